@@ -1,0 +1,69 @@
+// Shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../../include/mi_convnet.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define MCN_API extern "C" __attribute__((visibility("default")))
+
+void mcn_set_error(const char* fmt, ...);
+int mcn_check_hip(hipError_t e, const char* what);
+
+#define MCN_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            mcn_set_error(__VA_ARGS__);       \
+            return MCN_EINVAL;                \
+        }                                     \
+    } while (0)
+
+#define MCN_LAUNCH_CHECK(name) mcn_check_hip(hipGetLastError(), name)
+
+static inline int divup(int a, int b) { return (a + b - 1) / b; }
+static inline size_t divup_sz(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// v_mfma_f32_16x16x4_f32: lane l holds A[row=l&15][k=l>>4], B[k=l>>4][col=l&15];
+// acc[r] = D[row=(l>>4)*4+r][col=l&15].  Exact fp32 (k-ordered fma chain).
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Neuron functors (neuron.cuh:64-456), shared by the fused epilogues and the
+// stand-alone neuron kernels.  Exp/log/div are IEEE-accurate library versions;
+// the reference's fast intrinsics differ within the stated fp32 tolerance.
+__device__ __forceinline__ float neuron_apply(int type, float x, float a, float b) {
+    switch (type) {
+        case MCN_NEURON_RELU: return x < 0.f ? 0.f : x;
+        case MCN_NEURON_LOGISTIC: return 1.f / (1.f + expf(-x));
+        case MCN_NEURON_BRELU: return x < 0.f ? 0.f : (x > a ? a : x);
+        case MCN_NEURON_ABS: return fabsf(x);
+        case MCN_NEURON_TANH: return a * (2.f / (1.f + expf(x * (-2.f * b))) - 1.f);
+        case MCN_NEURON_SOFTRELU: return x > 4.f ? x : logf(1.f + expf(x));
+        case MCN_NEURON_SQUARE: return x * x;
+        case MCN_NEURON_SQRT: return sqrtf(x);
+        case MCN_NEURON_LINEAR: return a * x + b;
+        default: return x;
+    }
+}
+
+// gradient wrt the neuron input given dE/dy (g), the output y and the input x
+__device__ __forceinline__ float neuron_grad(int type, float g, float y, float x, float a, float b) {
+    switch (type) {
+        case MCN_NEURON_RELU: return g * (y > 0.f ? 1.f : 0.f);
+        case MCN_NEURON_LOGISTIC: return g * y * (1.f - y);
+        case MCN_NEURON_BRELU: return g * (y > 0.f ? 1.f : 0.f) * (y < a ? 1.f : 0.f);
+        case MCN_NEURON_ABS: return g * (x > 0.f ? 1.f : -1.f);
+        case MCN_NEURON_TANH: { const float t = (1.f - y / a) / 2.f; return g * (-4.f * a * b) * (t * (t - 1.f)); }
+        case MCN_NEURON_SOFTRELU: { if (y > 4.f) return g; const float e = expf(y); return g * (e / (1.f + e)); }
+        case MCN_NEURON_SQUARE: return g * 2.f * x;
+        case MCN_NEURON_SQRT: return g / (2.f * y);
+        case MCN_NEURON_LINEAR: return g * a;
+        default: return g;
+    }
+}
+
+static inline bool neuron_valid(int t) { return t >= 0 && t <= 9; }

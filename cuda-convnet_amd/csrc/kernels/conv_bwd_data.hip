@@ -1,0 +1,194 @@
+// imgActs (backward-data) for shared-weight conv and unshared local layers on fp32 MFMA.
+//
+// Replaces img_acts.cu:52-188 / :217-360 / :392-518 (+ host _imgActs :900-1912).
+// Gather form, like the reference: one wave owns one input pixel (y, x), 16*CV
+// channels of one group and 64*NQ images, and sums over the modules that cover
+// the pixel and over the group's filters:
+//   dImg[c, y, x, n] = sum_{m covers (y,x)} sum_f hid[f, m, n] * W[(m,) c*fp + p(y,x,m), f]
+// MFMA roles: A[row=c][k=f] from the weight rows (f is the contiguous dimension,
+// i.e. the REDUCTION index), B[k=f][col=n] from hidActs rows.  The reduction
+// index of an MFMA may be permuted as long as A and B agree, so each lane reads
+// 4 consecutive filters of its weight row with one 16-byte load and uses
+// component s in k-step s; the matching B rows are f = f16 + 4*kk + s.
+// No atomics, no LDS transposes; results are deterministic.
+#include "common.h"
+
+struct BwdDataParams {
+    const float* hidActs;
+    const float* filters;
+    float* targets;
+    int N, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups, conv;
+    float sT, sO;
+};
+
+template <int CV, int NQ, bool VECN>
+__global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
+    const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
+    const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int px = blockIdx.y * 4 + wave;
+    if (px >= imgPixels) return;
+    const int y = px / p.imgX, x = px % p.imgX;
+    const int n0 = blockIdx.x * (64 * NQ);
+    const int ctiles = (fc + 16 * CV - 1) / (16 * CV);
+    const int grp = blockIdx.z / ctiles;
+    const int c0 = (blockIdx.z % ctiles) * 16 * CV;  // channel within the group
+
+    // modules covering this pixel (img_acts.cu:435-440)
+    const int startY = y - p.pad < p.fs ? 0 : 1 + (y - p.pad - p.fs) / p.stride;
+    const int endY = min(p.mY, 1 + (y - p.pad) / p.stride);
+    const int startX = x - p.pad < p.fs ? 0 : 1 + (x - p.pad - p.fs) / p.stride;
+    const int endX = min(p.mX, 1 + (x - p.pad) / p.stride);
+
+    f32x4 acc[CV][NQ * 4];
+#pragma unroll
+    for (int v = 0; v < CV; v++)
+#pragma unroll
+        for (int t = 0; t < NQ * 4; t++) acc[v][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane weight row (channel) for each channel tile; rows beyond the group's channels are
+    // clamped (their outputs are never stored)
+    int crow[CV];
+#pragma unroll
+    for (int v = 0; v < CV; v++) crow[v] = min(c0 + 16 * v + j, fc - 1) * fp;
+
+    const float* hb = p.hidActs + (size_t)grp * fpg * M * p.N + n0 + 4 * j;
+    const float* wb = p.filters + (size_t)grp * fpg + 4 * kk;
+
+    for (int my = startY; my < endY; my++) {
+        const int pyf = y - (p.pad + my * p.stride);
+        for (int mx = startX; mx < endX; mx++) {
+            const int pxf = x - (p.pad + mx * p.stride);
+            const int m = my * p.mX + mx;
+            const int pf = pyf * p.fs + pxf;
+            const float* wm = wb + ((size_t)(p.conv ? 0 : m) * fc * fp + pf) * p.F;
+            const float* hm = hb + (size_t)m * p.N;
+            for (int f16 = 0; f16 < fpg; f16 += 16) {
+                f32x4 a[CV];
+#pragma unroll
+                for (int v = 0; v < CV; v++) a[v] = *reinterpret_cast<const f32x4*>(wm + (size_t)crow[v] * p.F + f16);
+                f32x4 b[4][NQ];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const float* hr = hm + (size_t)(f16 + 4 * kk + s) * M * p.N;
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int n = n0 + 64 * q + 4 * j;
+                        if (VECN) {
+                            b[s][q] = n < p.N ? *reinterpret_cast<const f32x4*>(hr + 64 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; t++) b[s][q][t] = n + t < p.N ? hr[64 * q + t] : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int v = 0; v < CV; v++)
+#pragma unroll
+                        for (int q = 0; q < NQ; q++)
+#pragma unroll
+                            for (int t = 0; t < 4; t++) acc[v][q * 4 + t] = mfma16(a[v][s], b[s][q][t], acc[v][q * 4 + t]);
+            }
+        }
+    }
+
+    // D row 4*kk + r of tile v <-> channel c0 + 16v + 4kk + r ; col j of MFMA t <-> image n0+64q+4j+t
+#pragma unroll
+    for (int v = 0; v < CV; v++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int c = c0 + 16 * v + 4 * kk + r;
+            if (c >= fc) continue;
+            float* trow = p.targets + ((size_t)(grp * fc + c) * imgPixels + px) * p.N;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int n = n0 + 64 * q + 4 * j;
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; t++) o[t] = p.sO * acc[v][q * 4 + t][r];
+                if (VECN) {
+                    if (n < p.N) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(trow + n);
+                        if (p.sT != 0.f) o += p.sT * (*dst);
+                        *dst = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (n + t < p.N) trow[n + t] = (p.sT != 0.f ? p.sT * trow[n + t] : 0.f) + o[t];
+                }
+            }
+        }
+    }
+}
+
+template <int CV, int NQ>
+static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, hipStream_t s) {
+    if (vecn) hipLaunchKernelGGL((k_img_acts<CV, NQ, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_img_acts<CV, NQ, false>), grid, dim3(256), 0, s, p);
+}
+
+template <int CV>
+static void launch_bd1(const BwdDataParams& p, int nq, dim3 grid, bool vecn, hipStream_t s) {
+    if (nq == 2) launch_bd2<CV, 2>(p, grid, vecn, s);
+    else launch_bd2<CV, 1>(p, grid, vecn, s);
+}
+
+static int img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int imgY, int imgX,
+                         int C, int F, int fs, int mY, int mX, int pad, int stride, int groups, int conv,
+                         float sT, float sO, void* stream) {
+    // host asserts of _imgActs (img_acts.cu:900-940)
+    MCN_REQUIRE(hidActs && filters && targets, "imgActs: null pointer");
+    MCN_REQUIRE(N > 0 && imgY > 0 && imgX > 0 && C > 0 && F > 0 && fs > 0 && mY > 0 && mX > 0 && stride > 0 && groups > 0,
+                "imgActs: non-positive dimension");
+    MCN_REQUIRE(C % groups == 0, "imgActs: numImgColors %% numGroups != 0");
+    MCN_REQUIRE(F % (16 * groups) == 0, "imgActs: numFilters (%d) must be divisible by 16*numGroups", F);
+    MCN_REQUIRE(groups > 1 || (C <= 3 || C % 2 == 0), "imgActs: numImgColors must be <= 3 or even");
+    MCN_REQUIRE(groups == 1 || (C / groups) % 4 == 0, "imgActs: filter colors must be divisible by 4 with groups");
+    MCN_REQUIRE(pad <= 0, "imgActs: paddingStart must be <= 0");
+    MCN_REQUIRE(pad + (mX - 1) * stride + fs >= imgX && pad + (mY - 1) * stride + fs >= imgY,
+                "imgActs: modules do not cover the image");
+    MCN_REQUIRE(stride <= fs, "imgActs: moduleStride > filterSize");
+    MCN_REQUIRE(((uintptr_t)filters % 16) == 0, "imgActs: filters must be 16-byte aligned");
+
+    BwdDataParams p;
+    p.hidActs = hidActs; p.filters = filters; p.targets = targets;
+    p.N = N; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs; p.mY = mY; p.mX = mX;
+    p.pad = pad; p.stride = stride; p.groups = groups; p.conv = conv; p.sT = sT; p.sO = sO;
+    const int fc = C / groups, imgPixels = imgY * imgX;
+    const bool vecn = (N % 4 == 0) && (((uintptr_t)hidActs | (uintptr_t)targets) % 16 == 0);
+    const int ct16 = divup(fc, 16);
+    int CV = ct16 >= 4 && ct16 % 4 == 0 ? 4 : ct16 % 3 == 0 ? 3 : ct16 % 2 == 0 ? 2 : 1;
+    int NQ = N > 64 ? 2 : 1;
+    auto waves = [&](int cv, int nq) { return (long)divup(N, 64 * nq) * imgPixels * groups * divup(fc, 16 * cv); };
+    if (waves(CV, NQ) < 1024 && NQ == 2) NQ = 1;
+    while (waves(CV, NQ) < 1024 && CV > 1) CV--;
+    dim3 grid(divup(N, 64 * NQ), divup(imgPixels, 4), groups * divup(fc, 16 * CV));
+    MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "imgActs: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    switch (CV) {
+        case 4: launch_bd1<4>(p, NQ, grid, vecn, s); break;
+        case 3: launch_bd1<3>(p, NQ, grid, vecn, s); break;
+        case 2: launch_bd1<2>(p, NQ, grid, vecn, s); break;
+        default: launch_bd1<1>(p, NQ, grid, vecn, s); break;
+    }
+    return MCN_LAUNCH_CHECK("imgActs");
+}
+
+MCN_API int mcn_conv_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int imgSizeY,
+                              int imgSizeX, int numImgColors, int numFilters, int filterSize, int numModulesY,
+                              int numModulesX, int paddingStart, int moduleStride, int numGroups, float scaleTargets,
+                              float scaleOutput, void* stream) {
+    return img_acts_impl(hidActs, filters, targets, numImages, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize,
+                         numModulesY, numModulesX, paddingStart, moduleStride, numGroups, 1, scaleTargets, scaleOutput, stream);
+}
+
+MCN_API int mcn_local_img_acts(const float* hidActs, const float* filters, float* targets, int numImages, int imgSizeY,
+                               int imgSizeX, int numImgColors, int numFilters, int filterSize, int numModulesY,
+                               int numModulesX, int paddingStart, int moduleStride, int numGroups, float scaleTargets,
+                               float scaleOutput, void* stream) {
+    return img_acts_impl(hidActs, filters, targets, numImages, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize,
+                         numModulesY, numModulesX, paddingStart, moduleStride, numGroups, 0, scaleTargets, scaleOutput, stream);
+}

@@ -1,0 +1,269 @@
+// weightActs (backward-weights) for shared-weight conv and unshared local layers on fp32 MFMA.
+//
+// Replaces weight_acts.cu:57-201 / :233-380 (+ host _weightActs :579-976) and, in
+// the *_reduced entry point, the (modules/partialSum) x weights temporary plus
+// addSum of ConvLayer::bpropWeights (layer.cu:476-496).
+//
+//   dW[(chunk,) k=(c,p), f] = sum_{m in chunk} sum_n img[c, pix(m,p), n] * hid[f, m, n]
+// MFMA roles: A[row=k][kk=n] from image rows, B[kk=n][col=f] from hidActs rows.
+// Both operands are contiguous along the REDUCTION index n, whose order inside
+// an MFMA chain is free as long as A and B agree: every lane reads 4 consecutive
+// images with one 16-byte load and uses component t in step t.  One wave owns
+// 16*KV weight rows x 16*FV filters for one module chunk; no LDS transposes.
+#include "common.h"
+
+struct BwdWParams {
+    const float* images;
+    const float* hidActs;
+    float* targets;
+    int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups;
+    int modulesPerChunk, check;
+    float sT, sO;
+};
+
+template <int KV, int FV, bool VECN>
+__global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
+    extern __shared__ int tbl[];
+    const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
+    const int K = fc * fp, M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
+    const int ktiles = (K + 16 * KV - 1) / (16 * KV);
+    const int Kpad = ktiles * 16 * KV;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        if (k < K) {
+            const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
+            tbl[2 * k] = c * imgPixels + fy * p.imgX + fx;
+            tbl[2 * k + 1] = (fy << 16) | fx;
+        } else {
+            tbl[2 * k] = 0;
+            tbl[2 * k + 1] = 0x40004000;
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int kt = blockIdx.y * 4 + wave;
+    if (kt >= ktiles) return;
+    const int chunk = blockIdx.x;
+    const int f0 = blockIdx.z * (16 * FV);
+    const int grp = f0 / fpg;
+    const int kb = kt * 16 * KV;
+    const bool check = p.check != 0;
+
+    int off[KV], yx[KV];
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        off[v] = tbl[2 * (kb + 16 * v + j)];
+        yx[v] = tbl[2 * (kb + 16 * v + j) + 1];
+    }
+    f32x4 acc[KV][FV];
+#pragma unroll
+    for (int v = 0; v < KV; v++)
+#pragma unroll
+        for (int u = 0; u < FV; u++) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* ig = p.images + (ptrdiff_t)grp * fc * imgPixels * p.imgStride + 4 * kk;
+    const float* hg = p.hidActs + (size_t)(f0 + j) * M * p.N + 4 * kk;
+
+    const int mBeg = chunk * p.modulesPerChunk, mEnd = min(M, mBeg + p.modulesPerChunk);
+    for (int m = mBeg; m < mEnd; m++) {
+        const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
+        const float* arow[KV];
+        bool ainb[KV];
+#pragma unroll
+        for (int v = 0; v < KV; v++) {
+            ainb[v] = kb + 16 * v + j < K;
+            if (check) ainb[v] = ainb[v] && (unsigned)(y0 + (yx[v] >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx[v] & 0xffff)) < (unsigned)p.imgX;
+            arow[v] = ig + ((ptrdiff_t)off[v] + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride;
+        }
+        const float* hm = hg + (size_t)m * p.N;
+        for (int nb = 0; nb < p.N; nb += 16) {
+            const int n = nb + 4 * kk;
+            f32x4 a[KV], b[FV];
+#pragma unroll
+            for (int v = 0; v < KV; v++) {
+                if (VECN) {
+                    a[v] = (ainb[v] && n < p.N) ? *reinterpret_cast<const f32x4*>(arow[v] + nb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) a[v][t] = (ainb[v] && n + t < p.N) ? arow[v][nb + t] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < FV; u++) {
+                const float* hr = hm + (size_t)(16 * u) * M * p.N + nb;
+                if (VECN) {
+                    b[u] = n < p.N ? *reinterpret_cast<const f32x4*>(hr) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) b[u][t] = n + t < p.N ? hr[t] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int v = 0; v < KV; v++)
+#pragma unroll
+                    for (int u = 0; u < FV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+        }
+    }
+
+    // D row 4kk+r of tile v <-> weight row kb+16v+4kk+r ; col j of tile u <-> filter f0+16u+j
+#pragma unroll
+    for (int v = 0; v < KV; v++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int k = kb + 16 * v + 4 * kk + r;
+            if (k >= K) continue;
+            float* trow = p.targets + ((size_t)chunk * K + k) * p.F + f0 + j;
+#pragma unroll
+            for (int u = 0; u < FV; u++) {
+                const float o = p.sO * acc[v][u][r];
+                trow[16 * u] = p.sT != 0.f ? p.sT * trow[16 * u] + o : o;
+            }
+        }
+}
+
+// column sums of the (chunks x cols) partials in a fixed order: grad = sT*grad + sum
+__global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__ part, float* __restrict__ grad,
+                                                       int chunks, int cols, float sT) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < chunks; r += 4) {
+        s0 += part[(size_t)r * cols + c];
+        s1 += part[(size_t)(r + 1) * cols + c];
+        s2 += part[(size_t)(r + 2) * cols + c];
+        s3 += part[(size_t)(r + 3) * cols + c];
+    }
+    for (; r < chunks; r++) s0 += part[(size_t)r * cols + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    grad[c] = sT != 0.f ? sT * grad[c] + s : s;
+}
+
+template <int KV, int FV>
+static void launch_bw2(const BwdWParams& p, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
+    if (vecn) hipLaunchKernelGGL((k_weight_acts<KV, FV, true>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_weight_acts<KV, FV, false>), grid, dim3(256), lds, s, p);
+}
+
+static int weight_acts_check(const float* images, const float* hidActs, float* targets, int N, int imgStride,
+                             int imgY, int imgX, int C, int F, int fs, int mY, int mX, int pad, int stride, int groups) {
+    // host asserts of _weightActs (weight_acts.cu:579-620)
+    MCN_REQUIRE(images && hidActs && targets, "weightActs: null pointer");
+    MCN_REQUIRE(N > 0 && imgY > 0 && imgX > 0 && C > 0 && F > 0 && fs > 0 && mY > 0 && mX > 0 && stride > 0 && groups > 0,
+                "weightActs: non-positive dimension");
+    MCN_REQUIRE(imgStride >= N, "weightActs: imgStride (%d) < numImages (%d)", imgStride, N);
+    MCN_REQUIRE(C % groups == 0, "weightActs: numImgColors %% numGroups != 0");
+    MCN_REQUIRE(F % (16 * groups) == 0, "weightActs: numFilters (%d) must be divisible by 16*numGroups", F);
+    MCN_REQUIRE(groups > 1 || (C <= 3 || C % 2 == 0), "weightActs: numImgColors must be <= 3 or even");
+    MCN_REQUIRE(groups == 1 || (C / groups) % 4 == 0, "weightActs: filter colors must be divisible by 4 with groups");
+    MCN_REQUIRE(pad <= 0, "weightActs: paddingStart must be <= 0");
+    MCN_REQUIRE(pad + (mX - 1) * stride + fs >= imgX && pad + (mY - 1) * stride + fs >= imgY,
+                "weightActs: modules do not cover the image");
+    MCN_REQUIRE(stride <= fs, "weightActs: moduleStride > filterSize");
+    return MCN_OK;
+}
+
+// modulesPerChunk modules are summed per output slab; targets has divup(M, modulesPerChunk) slabs.
+static int weight_acts_launch(const float* images, const float* hidActs, float* targets, int N, int imgStride,
+                              int imgY, int imgX, int C, int F, int fs, int mY, int mX, int pad, int stride,
+                              int groups, int modulesPerChunk, float sT, float sO, hipStream_t s) {
+    BwdWParams p;
+    p.images = images; p.hidActs = hidActs; p.targets = targets;
+    p.N = N; p.imgStride = imgStride; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs;
+    p.mY = mY; p.mX = mX; p.pad = pad; p.stride = stride; p.groups = groups;
+    p.modulesPerChunk = modulesPerChunk; p.sT = sT; p.sO = sO;
+    const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
+    p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY);
+    const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)hidActs) % 16 == 0);
+    const int chunks = divup(M, modulesPerChunk);
+    const int ftiles = fpg / 16;
+    int FV = ftiles % 2 == 0 ? 2 : 1;
+    const int kt16 = divup(K, 16);
+    int KV = kt16 >= 3 ? 3 : kt16;
+    auto waves = [&](int kv, int fv) { return (long)chunks * divup(K, 16 * kv) * (F / (16 * fv)); };
+    while (waves(KV, FV) < 1024 && KV > 1) KV--;
+    if (waves(KV, FV) < 1024 && FV == 2) FV = 1;
+    const int ktiles = divup(K, 16 * KV);
+    dim3 grid(chunks, divup(ktiles, 4), F / (16 * FV));
+    MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "weightActs: grid too large");
+    const size_t lds = (size_t)ktiles * 16 * KV * 8;
+    MCN_REQUIRE(lds <= 64 * 1024, "weightActs: filter too large for the decode table (%zu bytes)", lds);
+    if (KV == 3 && FV == 2) launch_bw2<3, 2>(p, grid, lds, vecn, s);
+    else if (KV == 3) launch_bw2<3, 1>(p, grid, lds, vecn, s);
+    else if (KV == 2 && FV == 2) launch_bw2<2, 2>(p, grid, lds, vecn, s);
+    else if (KV == 2) launch_bw2<2, 1>(p, grid, lds, vecn, s);
+    else if (FV == 2) launch_bw2<1, 2>(p, grid, lds, vecn, s);
+    else launch_bw2<1, 1>(p, grid, lds, vecn, s);
+    return MCN_LAUNCH_CHECK("weightActs");
+}
+
+MCN_API int mcn_conv_weight_acts(const float* images, const float* hidActs, float* targets, int numImages,
+                                 int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                 int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                 int numGroups, int partialSum, float scaleTargets, float scaleOutput, void* stream) {
+    int rc = weight_acts_check(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                               numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
+    if (rc) return rc;
+    const int M = numModulesY * numModulesX;
+    if (partialSum <= 0) partialSum = M;
+    MCN_REQUIRE(M % partialSum == 0, "convWeightActs: partialSum (%d) must divide the number of modules (%d)", partialSum, M);
+    return weight_acts_launch(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                              numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
+                              partialSum, scaleTargets, scaleOutput, (hipStream_t)stream);
+}
+
+MCN_API int mcn_local_weight_acts(const float* images, const float* hidActs, float* targets, int numImages,
+                                  int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                  int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                  int numGroups, float scaleTargets, float scaleOutput, void* stream) {
+    int rc = weight_acts_check(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                               numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
+    if (rc) return rc;
+    return weight_acts_launch(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                              numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
+                              1, scaleTargets, scaleOutput, (hipStream_t)stream);
+}
+
+// module split of the fused reduction: enough chunks to fill the chip, few enough to keep the
+// second pass negligible
+static int reduced_modules_per_chunk(int M, int K, int F) {
+    const long tilesPerChunk = (long)divup(K, 48) * (F / 16);
+    long want = divup(2048, (int)(tilesPerChunk > 0 ? tilesPerChunk : 1));  // chunks wanted
+    if (want < 1) want = 1;
+    if (want > M) want = M;
+    return divup(M, (int)want);
+}
+
+MCN_API size_t mcn_conv_weight_acts_reduced_workspace_bytes(int numImgColors, int numFilters, int filterSize,
+                                                            int numModulesY, int numModulesX, int numGroups) {
+    const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
+    const int mpc = reduced_modules_per_chunk(M, K, numFilters);
+    return (size_t)divup(M, mpc) * K * numFilters * sizeof(float);
+}
+
+MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, float* grad, void* workspace,
+                                         size_t workspaceBytes, int numImages, int imgStride, int imgSizeY,
+                                         int imgSizeX, int numImgColors, int numFilters, int filterSize,
+                                         int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                         int numGroups, float scaleTargets, float scaleOutput, void* stream) {
+    int rc = weight_acts_check(images, hidActs, grad, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                               numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
+    if (rc) return rc;
+    const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
+    const int mpc = reduced_modules_per_chunk(M, K, numFilters);
+    const int chunks = divup(M, mpc);
+    const size_t need = (size_t)chunks * K * numFilters * sizeof(float);
+    if (workspaceBytes < need || !workspace) {
+        mcn_set_error("convWeightActsReduced: workspace %zu < %zu bytes", workspaceBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    rc = weight_acts_launch(images, hidActs, (float*)workspace, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                            numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
+                            mpc, 0.f, scaleOutput, (hipStream_t)stream);
+    if (rc) return rc;
+    const int cols = K * numFilters;
+    hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, grad, chunks, cols, scaleTargets);
+    return MCN_LAUNCH_CHECK("convWeightActsReduced");
+}

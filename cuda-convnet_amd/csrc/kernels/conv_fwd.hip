@@ -1,0 +1,222 @@
+// filterActs for shared-weight conv and unshared local layers on fp32 MFMA.
+//
+// Replaces filter_acts.cu:56-192 / :223-368 (+ host _filterActs :565-1180) and,
+// through the fused epilogue, the bias addVector of layer.cu:453-461 / :540-542
+// and the in-place neuron of layer.cu:249.
+//
+// Implicit GEMM per module m:  out[f, n] = sum_k W[(m,) k, f] * patch_m[k, n],
+// k = (c, fy, fx).  One wave owns (one module) x (16*FV filters) x (64*NQ images).
+// v_mfma_f32_16x16x4_f32 operands come straight from the reference layouts:
+//   A[row=f][k]  : lane (i=l&15, kk=l>>4) reads FV consecutive filters of weight row k0+kk
+//   B[k][col=n]  : lane (j=l&15, kk=l>>4) reads 4 consecutive images of patch row k0+kk
+// Because both the M (filter) and N (image) index of an MFMA may be permuted
+// freely, component u of the A vector / t of the B vector feed MFMA (u,t): 16-byte
+// loads along the contiguous dimensions and 16-byte stores, no LDS transposes.
+// The k -> (channel,fy,fx) decode is tabulated once per workgroup in LDS.
+#include "common.h"
+
+struct FwdParams {
+    const float* images;
+    const float* filters;
+    const float* biases;
+    float* targets;
+    int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups;
+    int conv, check, biasPerModule, neuron;
+    float sT, sO, na, nb;
+};
+
+template <int FV>
+struct AVec { float v[FV]; };
+
+template <int FV, int NQ, bool VECN>
+__global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
+    extern __shared__ int tbl[];
+    const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
+    const int K = fc * fp, K4 = (K + 3) & ~3, M = p.mY * p.mX;
+    const int imgPixels = p.imgY * p.imgX;
+    for (int k = threadIdx.x; k < K4; k += 256) {
+        if (k < K) {
+            const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
+            tbl[2 * k] = c * imgPixels + fy * p.imgX + fx;
+            tbl[2 * k + 1] = (fy << 16) | fx;
+        } else {
+            tbl[2 * k] = 0;
+            tbl[2 * k + 1] = 0x40004000;  // far out of bounds: contributes zero
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int m = blockIdx.y * 4 + wave;
+    if (m >= M) return;
+    const int n0 = blockIdx.x * (64 * NQ);
+    const int f0 = blockIdx.z * (16 * FV);
+    const int grp = f0 / fpg;
+    const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
+    const bool check = p.check != 0;
+
+    const float* ib = p.images + ((ptrdiff_t)grp * fc * imgPixels + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride + n0 + 4 * j;
+    const float* wb = p.filters + (size_t)(p.conv ? 0 : m) * K * p.F + f0 + FV * j;
+
+    f32x4 acc[FV][NQ * 4];
+#pragma unroll
+    for (int u = 0; u < FV; u++)
+#pragma unroll
+        for (int t = 0; t < NQ * 4; t++) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + kk;
+        const int off = tbl[2 * k], yx = tbl[2 * k + 1];
+        const int kc = k < K ? k : K - 1;
+        const AVec<FV> a = *reinterpret_cast<const AVec<FV>*>(wb + (size_t)kc * p.F);
+        bool inb = k < K;
+        if (check) inb = inb && (unsigned)(y0 + (yx >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx & 0xffff)) < (unsigned)p.imgX;
+        const float* src = ib + (ptrdiff_t)off * p.imgStride;
+        f32x4 b[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int n = n0 + 64 * q + 4 * j;
+            if (VECN) {
+                b[q] = (inb && n < p.N) ? *reinterpret_cast<const f32x4*>(src + 64 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) b[q][t] = (inb && n + t < p.N) ? src[64 * q + t] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FV; u++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[u][q * 4 + t] = mfma16(a.v[u], b[q][t], acc[u][q * 4 + t]);
+    }
+
+    // D row (4*kk + r) of MFMA u  <->  filter f0 + FV*(4*kk + r) + u ; col j, MFMA t <-> image n0+64q+4j+t
+#pragma unroll
+    for (int u = 0; u < FV; u++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = f0 + FV * (4 * kk + r) + u;
+            float bias = 0.f;
+            if (p.biases) bias = p.biases[p.biasPerModule ? (size_t)f * M + m : f];
+            float* trow = p.targets + ((size_t)f * M + m) * p.N;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int n = n0 + 64 * q + 4 * j;
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = p.sO * acc[u][q * 4 + t][r] + bias;
+                if (p.neuron != MCN_NEURON_IDENT) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[t] = neuron_apply(p.neuron, v[t], p.na, p.nb);
+                }
+                if (VECN) {
+                    if (n < p.N) {
+                        f32x4* dst = reinterpret_cast<f32x4*>(trow + n);
+                        if (p.sT != 0.f) v += p.sT * (*dst);
+                        *dst = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        if (n + t < p.N) trow[n + t] = (p.sT != 0.f ? p.sT * trow[n + t] : 0.f) + v[t];
+                }
+            }
+        }
+    }
+}
+
+template <int FV, int NQ>
+static void launch_fwd2(const FwdParams& p, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
+    if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, true>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_filter_acts<FV, NQ, false>), grid, dim3(256), lds, s, p);
+}
+
+template <int FV>
+static void launch_fwd1(const FwdParams& p, int nq, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
+    if (nq == 2) launch_fwd2<FV, 2>(p, grid, lds, vecn, s);
+    else launch_fwd2<FV, 1>(p, grid, lds, vecn, s);
+}
+
+static int filter_acts_impl(const float* images, const float* filters, const float* biases, float* targets,
+                            int N, int imgStride, int imgY, int imgX, int C, int F, int fs, int mY, int mX,
+                            int pad, int stride, int groups, int conv, float sT, float sO, int biasPerModule,
+                            int neuron, float na, float nb, void* stream) {
+    // host asserts of _filterActs (filter_acts.cu:577-614), reported instead of aborting
+    MCN_REQUIRE(images && filters && targets, "filterActs: null pointer");
+    MCN_REQUIRE(N > 0 && imgY > 0 && imgX > 0 && C > 0 && F > 0 && fs > 0 && mY > 0 && mX > 0 && stride > 0 && groups > 0,
+                "filterActs: non-positive dimension");
+    MCN_REQUIRE(imgStride >= N, "filterActs: imgStride (%d) < numImages (%d)", imgStride, N);
+    MCN_REQUIRE(C % groups == 0, "filterActs: numImgColors %% numGroups != 0");
+    MCN_REQUIRE(F % (16 * groups) == 0, "filterActs: numFilters (%d) must be divisible by 16*numGroups", F);
+    MCN_REQUIRE(groups > 1 || (C <= 3 || C % 2 == 0), "filterActs: numImgColors must be <= 3 or even");
+    MCN_REQUIRE(groups == 1 || (C / groups) % 2 == 0, "filterActs: filter colors must be even with groups");
+    MCN_REQUIRE(pad <= 0, "filterActs: paddingStart must be <= 0");
+    MCN_REQUIRE(pad + (mX - 1) * stride + fs >= imgX && pad + (mY - 1) * stride + fs >= imgY,
+                "filterActs: modules do not cover the image");
+    MCN_REQUIRE(stride <= fs, "filterActs: moduleStride > filterSize");
+    MCN_REQUIRE(neuron_valid(neuron), "filterActs: bad neuron type %d", neuron);
+
+    FwdParams p;
+    p.images = images; p.filters = filters; p.biases = biases; p.targets = targets;
+    p.N = N; p.imgStride = imgStride; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs;
+    p.mY = mY; p.mX = mX; p.pad = pad; p.stride = stride; p.groups = groups;
+    p.conv = conv; p.biasPerModule = biasPerModule; p.neuron = neuron;
+    p.sT = sT; p.sO = sO; p.na = na; p.nb = nb;
+    const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
+    p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY) || (K % 4 != 0);
+
+    const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)targets) % 16 == 0);
+    // tile choice: largest filter vector that divides the group's filter tiles, then shrink until
+    // the launch has at least one wave per SIMD (1024 on MI355X)
+    const int ftiles = fpg / 16;
+    int FV = ftiles % 4 == 0 ? 4 : ftiles % 3 == 0 ? 3 : ftiles % 2 == 0 ? 2 : 1;
+    int NQ = N > 64 ? 2 : 1;
+    auto waves = [&](int fv, int nq) { return (long)divup(N, 64 * nq) * M * (F / (16 * fv)); };
+    if (waves(FV, NQ) < 1024 && NQ == 2) NQ = 1;
+    while (waves(FV, NQ) < 1024 && FV > 1) {
+        int nf = FV - 1;
+        while (nf > 1 && ftiles % nf != 0) nf--;
+        FV = nf;
+    }
+    dim3 grid(divup(N, 64 * NQ), divup(M, 4), F / (16 * FV));
+    MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "filterActs: grid too large");
+    const size_t lds = (size_t)((K + 3) & ~3) * 8;
+    MCN_REQUIRE(lds <= 64 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
+    hipStream_t s = (hipStream_t)stream;
+    switch (FV) {
+        case 4: launch_fwd1<4>(p, NQ, grid, lds, vecn, s); break;
+        case 3: launch_fwd1<3>(p, NQ, grid, lds, vecn, s); break;
+        case 2: launch_fwd1<2>(p, NQ, grid, lds, vecn, s); break;
+        default: launch_fwd1<1>(p, NQ, grid, lds, vecn, s); break;
+    }
+    return MCN_LAUNCH_CHECK("filterActs");
+}
+
+MCN_API int mcn_conv_filter_acts(const float* images, const float* filters, float* targets, int numImages,
+                                 int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                 int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                                 int moduleStride, int numGroups, float scaleTargets, float scaleOutput, void* stream) {
+    return filter_acts_impl(images, filters, nullptr, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                            numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups, 1,
+                            scaleTargets, scaleOutput, 0, MCN_NEURON_IDENT, 0.f, 0.f, stream);
+}
+
+MCN_API int mcn_local_filter_acts(const float* images, const float* filters, float* targets, int numImages,
+                                  int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                  int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                                  int moduleStride, int numGroups, float scaleTargets, float scaleOutput, void* stream) {
+    return filter_acts_impl(images, filters, nullptr, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                            numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups, 0,
+                            scaleTargets, scaleOutput, 0, MCN_NEURON_IDENT, 0.f, 0.f, stream);
+}
+
+MCN_API int mcn_filter_acts_bias_neuron(const float* images, const float* filters, const float* biases, float* targets,
+                                        int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                        int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                        int paddingStart, int moduleStride, int numGroups, int conv,
+                                        int biasPerModule, int neuron, float neuronA, float neuronB, void* stream) {
+    return filter_acts_impl(images, filters, biases, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                            numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
+                            conv ? 1 : 0, 0.f, 1.f, biasPerModule, neuron, neuronA, neuronB, stream);
+}

@@ -1,0 +1,645 @@
+// Element-wise / reduction / cost kernels: neurons, NVMatrix verbs, softmax,
+// logistic-regression cost and gradients, the Joint identification-verification
+// (L2-SN) cost and gradient, L2 regression cost, and the fused SGD update.
+//
+// Replaces nvmatrix_kernels.cuh:91-265 (eltwise + vector ops), :272-593
+// (aggregations), layer_kernels.cu:59-170 / :482-794 and weights.cuh:150-163.
+// All are HBM- or latency-bound; they use 16-byte accesses along the contiguous
+// dimension and fixed-order reductions (deterministic results).
+#include <algorithm>
+#include "common.h"
+
+#define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
+
+static inline unsigned ew_blocks(size_t n, int per = 256) { return (unsigned)std::min<size_t>(divup_sz(n, per), 16384); }
+static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+// ---------------------------------------------------------------- neurons
+__global__ __launch_bounds__(256) void k_neuron_fwd(const float* in, float* out, size_t n, int type, float a, float b) {
+    GRID_STRIDE(i, n) out[i] = neuron_apply(type, in[i], a, b);
+}
+__global__ __launch_bounds__(256) void k_relu_fwd4(const f32x4* in, f32x4* out, size_t n4) {
+    GRID_STRIDE(i, n4) {
+        f32x4 v = in[i];
+        for (int t = 0; t < 4; t++) v[t] = v[t] < 0.f ? 0.f : v[t];
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_neuron_bwd(const float* g, const float* acts, const float* inputs, float* target,
+                                                    size_t n, int type, float a, float b, int add) {
+    GRID_STRIDE(i, n) {
+        const float v = neuron_grad(type, g[i], acts ? acts[i] : 0.f, inputs ? inputs[i] : 0.f, a, b);
+        target[i] = add ? target[i] + v : v;
+    }
+}
+__global__ __launch_bounds__(256) void k_relu_bwd4(const f32x4* g, const f32x4* acts, f32x4* target, size_t n4, int add) {
+    GRID_STRIDE(i, n4) {
+        f32x4 v = g[i];
+        const f32x4 y = acts[i];
+        for (int t = 0; t < 4; t++) v[t] = v[t] * (y[t] > 0.f ? 1.f : 0.f);
+        if (add) v += target[i];
+        target[i] = v;
+    }
+}
+
+MCN_API int mcn_neuron_fwd(const float* in, float* out, size_t n, int neuron, float a, float b, void* stream) {
+    MCN_REQUIRE(in && out && neuron_valid(neuron), "neuronFwd: bad argument");
+    if (n == 0) return MCN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (neuron == MCN_NEURON_IDENT) {
+        if (in != out) return mcn_check_hip(hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, s), "neuronFwd copy");
+        return MCN_OK;
+    }
+    if (neuron == MCN_NEURON_RELU && n % 4 == 0 && al16(in) && al16(out))
+        hipLaunchKernelGGL(k_relu_fwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)in, (f32x4*)out, n / 4);
+    else
+        hipLaunchKernelGGL(k_neuron_fwd, dim3(ew_blocks(n)), dim3(256), 0, s, in, out, n, neuron, a, b);
+    return MCN_LAUNCH_CHECK("neuronFwd");
+}
+
+MCN_API int mcn_neuron_bwd(const float* actsGrad, const float* acts, const float* inputs, float* target, size_t n,
+                           int neuron, float a, float b, int add, void* stream) {
+    MCN_REQUIRE(actsGrad && target && neuron_valid(neuron), "neuronBwd: bad argument");
+    const bool needsIn = neuron == MCN_NEURON_ABS || neuron == MCN_NEURON_SQUARE;
+    const bool needsAct = !needsIn && neuron != MCN_NEURON_IDENT && neuron != MCN_NEURON_LINEAR;
+    MCN_REQUIRE(!needsIn || inputs, "neuronBwd: neuron %d needs its inputs", neuron);
+    MCN_REQUIRE(!needsAct || acts, "neuronBwd: neuron %d needs its outputs", neuron);
+    if (n == 0) return MCN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (neuron == MCN_NEURON_IDENT && !add && target == actsGrad) return MCN_OK;
+    if (neuron == MCN_NEURON_RELU && n % 4 == 0 && al16(actsGrad) && al16(acts) && al16(target))
+        hipLaunchKernelGGL(k_relu_bwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)actsGrad, (const f32x4*)acts,
+                           (f32x4*)target, n / 4, add);
+    else
+        hipLaunchKernelGGL(k_neuron_bwd, dim3(ew_blocks(n)), dim3(256), 0, s, actsGrad, acts, inputs, target, n, neuron, a, b, add);
+    return MCN_LAUNCH_CHECK("neuronBwd");
+}
+
+// ---------------------------------------------------------------- NVMatrix verbs
+__global__ __launch_bounds__(256) void k_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale) {
+    const size_t n = (size_t)rows * cols;
+    GRID_STRIDE(i, n) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        mat[i] += scale * (perRow ? vec[r] : vec[c]);
+    }
+}
+MCN_API int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream) {
+    MCN_REQUIRE(mat && vec && rows > 0 && cols > 0, "addVector: bad argument");
+    hipLaunchKernelGGL(k_add_vector, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, mat, vec, rows, cols, perRow, scale);
+    return MCN_LAUNCH_CHECK("addVector");
+}
+
+// Row sums.  Stage 1: block (row, chunk) reduces CH columns in a fixed order -> partial[row][chunk].
+// Stage 2 (or the only stage when one chunk covers the row): tgt = scaleThis*tgt + scaleSum*sum.
+#define ROWSUM_CHUNK 8192
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ mat, float* __restrict__ out, int cols, int chunks,
+                                                 int finalStage, float scaleThis, float scaleSum) {
+    __shared__ float sh[4];
+    const int row = blockIdx.x, chunk = blockIdx.y;
+    const int c0 = chunk * ROWSUM_CHUNK, c1 = min(cols, c0 + ROWSUM_CHUNK);
+    const float* m = mat + (size_t)row * cols;
+    float v = 0.f;
+    for (int c = c0 + threadIdx.x; c < c1; c += 256) v += m[c];
+    const float s = block_sum256(v, sh);
+    if (threadIdx.x == 0) {
+        if (finalStage) out[row] = (scaleThis != 0.f ? scaleThis * out[row] : 0.f) + scaleSum * s;
+        else out[(size_t)row * chunks + chunk] = s;
+    }
+}
+// short rows (cols <= 256): one wave per row, 4 rows per block
+__global__ __launch_bounds__(256) void k_row_sum_short(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols,
+                                                       float scaleThis, float scaleSum) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* m = mat + (size_t)row * cols;
+    float v = 0.f;
+    for (int c = lane; c < cols; c += 64) v += m[c];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) out[row] = (scaleThis != 0.f ? scaleThis * out[row] : 0.f) + scaleSum * v;
+}
+__global__ __launch_bounds__(256) void k_col_sum(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols,
+                                                 float scaleThis, float scaleSum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        s0 += mat[(size_t)r * cols + c];
+        s1 += mat[(size_t)(r + 1) * cols + c];
+        s2 += mat[(size_t)(r + 2) * cols + c];
+        s3 += mat[(size_t)(r + 3) * cols + c];
+    }
+    for (; r < rows; r++) s0 += mat[(size_t)r * cols + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[c] = (scaleThis != 0.f ? scaleThis * out[c] : 0.f) + scaleSum * s;
+}
+
+MCN_API size_t mcn_add_sum_workspace_bytes(int rows, int cols, int axis) {
+    if (axis != 1 || cols <= ROWSUM_CHUNK) return 0;
+    return (size_t)rows * divup(cols, ROWSUM_CHUNK) * sizeof(float);
+}
+MCN_API int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int axis, float scaleThis, float scaleSum,
+                        void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(tgt && mat && rows > 0 && cols > 0 && (axis == 0 || axis == 1), "addSum: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (axis == 0) {
+        hipLaunchKernelGGL(k_col_sum, dim3(divup(cols, 256)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
+    } else if (cols <= 256) {
+        hipLaunchKernelGGL(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
+    } else if (cols <= ROWSUM_CHUNK) {
+        hipLaunchKernelGGL(k_row_sum, dim3(rows, 1), dim3(256), 0, s, mat, tgt, cols, 1, 1, scaleThis, scaleSum);
+    } else {
+        const int chunks = divup(cols, ROWSUM_CHUNK);
+        const size_t need = (size_t)rows * chunks * sizeof(float);
+        if (!workspace || workspaceBytes < need) {
+            mcn_set_error("addSum: workspace %zu < %zu bytes", workspaceBytes, need);
+            return MCN_EWORKSPACE;
+        }
+        MCN_REQUIRE(chunks <= 65535, "addSum: row too long");
+        hipLaunchKernelGGL(k_row_sum, dim3(rows, chunks), dim3(256), 0, s, mat, (float*)workspace, cols, chunks, 0, 0.f, 1.f);
+        if (chunks <= 256)
+            hipLaunchKernelGGL(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, (const float*)workspace, tgt, rows, chunks, scaleThis, scaleSum);
+        else
+            hipLaunchKernelGGL(k_row_sum, dim3(rows, 1), dim3(256), 0, s, (const float*)workspace, tgt, chunks, 1, 1, scaleThis, scaleSum);
+    }
+    return MCN_LAUNCH_CHECK("addSum");
+}
+
+__global__ __launch_bounds__(256) void k_axpby(float* a, const float* b, size_t n, float sa, float sb) {
+    GRID_STRIDE(i, n) a[i] = sa * a[i] + sb * b[i];
+}
+MCN_API int mcn_axpby(float* a, const float* b, size_t n, float sa, float sb, void* stream) {
+    MCN_REQUIRE(a && b, "axpby: null pointer");
+    if (n == 0) return MCN_OK;
+    hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, sa, sb);
+    return MCN_LAUNCH_CHECK("axpby");
+}
+__global__ __launch_bounds__(256) void k_scale(const float* in, float* out, size_t n, float sc) {
+    GRID_STRIDE(i, n) out[i] = sc * in[i];
+}
+MCN_API int mcn_scale(const float* in, float* out, size_t n, float sc, void* stream) {
+    MCN_REQUIRE(in && out, "scale: null pointer");
+    if (n == 0) return MCN_OK;
+    hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, sc);
+    return MCN_LAUNCH_CHECK("scale");
+}
+__global__ __launch_bounds__(256) void k_eltmax(const float* a, const float* b, float* out, size_t n) {
+    GRID_STRIDE(i, n) out[i] = fmaxf(a[i], b[i]);
+}
+MCN_API int mcn_eltwise_max(const float* a, const float* b, float* out, size_t n, void* stream) {
+    MCN_REQUIRE(a && b && out, "eltwiseMax: null pointer");
+    if (n == 0) return MCN_OK;
+    hipLaunchKernelGGL(k_eltmax, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return MCN_LAUNCH_CHECK("eltwiseMax");
+}
+__global__ __launch_bounds__(256) void k_eltmax_grad(const float* g, const float* in, const float* out, float* tgt, size_t n, int add) {
+    GRID_STRIDE(i, n) {
+        const float v = g[i] * (out[i] == in[i] ? 1.f : 0.f);
+        tgt[i] = add ? tgt[i] + v : v;
+    }
+}
+MCN_API int mcn_eltwise_max_grad(const float* actGrad, const float* input, const float* output, float* target, size_t n,
+                                 int add, void* stream) {
+    MCN_REQUIRE(actGrad && input && output && target, "eltwiseMaxGrad: null pointer");
+    if (n == 0) return MCN_OK;
+    hipLaunchKernelGGL(k_eltmax_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, actGrad, input, output, target, n, add);
+    return MCN_LAUNCH_CHECK("eltwiseMaxGrad");
+}
+
+// total sum: single block (inputs on this path are cost vectors of <= a few thousand entries)
+__global__ __launch_bounds__(256) void k_sum_all(const float* a, size_t n, double* out, int accumulate) {
+    __shared__ double sh[256];
+    double v = 0;
+    for (size_t i = threadIdx.x; i < n; i += 256) v += (double)a[i];
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = (accumulate ? *out : 0.0) + sh[0];
+}
+MCN_API int mcn_sum_all(const float* a, size_t n, double* outDevice, int accumulate, void* stream) {
+    MCN_REQUIRE(a && outDevice, "sumAll: null pointer");
+    hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, (hipStream_t)stream, a, n, outDevice, accumulate);
+    return MCN_LAUNCH_CHECK("sumAll");
+}
+
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (by + r < rows && bx + tx < cols) tile[r][tx] = src[(size_t)(by + r) * cols + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < cols && by + tx < rows) dst[(size_t)(bx + r) * rows + by + tx] = tile[tx][r];
+}
+MCN_API int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
+    MCN_REQUIRE(src && dst && rows > 0 && cols > 0 && src != dst, "transpose: bad argument");
+    hipLaunchKernelGGL(k_transpose, dim3(divup(cols, 32), divup(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    return MCN_LAUNCH_CHECK("transpose");
+}
+
+// ---------------------------------------------------------------- softmax
+// x, p are (numOut, numCases) row-major; the softmax runs down each column.  Stage 1: block
+// (caseTile of 64, rowChunk) computes per-column (max, sum exp(x - max)) over its rows; stage 2
+// merges the chunk partials in chunk order and writes p = exp(x - M) / S.
+#define SM_ROWS 256  // rows per chunk
+__global__ __launch_bounds__(256) void k_softmax_partial(const float* __restrict__ x, float* __restrict__ part, int numOut, int numCases, int chunks) {
+    __shared__ float shm[4][64], shs[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
+    const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
+    float m = -INFINITY, s = 0.f;
+    if (col < numCases) {
+        for (int r = r0 + rl; r < r1; r += 4) m = fmaxf(m, x[(size_t)r * numCases + col]);
+    }
+    shm[rl][threadIdx.x & 63] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(shm[0][threadIdx.x & 63], shm[1][threadIdx.x & 63]), fmaxf(shm[2][threadIdx.x & 63], shm[3][threadIdx.x & 63]));
+    if (col < numCases) {
+        for (int r = r0 + rl; r < r1; r += 4) s += expf(x[(size_t)r * numCases + col] - m);
+    }
+    shs[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < numCases) {
+        s = (shs[0][threadIdx.x] + shs[1][threadIdx.x]) + (shs[2][threadIdx.x] + shs[3][threadIdx.x]);
+        part[((size_t)chunk * numCases + col) * 2] = m;
+        part[((size_t)chunk * numCases + col) * 2 + 1] = s;
+    }
+}
+__global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
+                                                       int numOut, int numCases, int chunks) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
+    if (col >= numCases) return;
+    float M = -INFINITY;
+    for (int c = 0; c < chunks; c++) M = fmaxf(M, part[((size_t)c * numCases + col) * 2]);
+    float S = 0.f;
+    for (int c = 0; c < chunks; c++) S += part[((size_t)c * numCases + col) * 2 + 1] * expf(part[((size_t)c * numCases + col) * 2] - M);
+    const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
+    for (int r = r0 + rl; r < r1; r += 4) p[(size_t)r * numCases + col] = expf(x[(size_t)r * numCases + col] - M) / S;
+}
+MCN_API size_t mcn_softmax_workspace_bytes(int numOut, int numCases) {
+    return (size_t)divup(numOut, SM_ROWS) * numCases * 2 * sizeof(float);
+}
+MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(x && probs && numOut > 0 && numCases > 0, "softmax: bad argument");
+    const int chunks = divup(numOut, SM_ROWS);
+    const size_t need = mcn_softmax_workspace_bytes(numOut, numCases);
+    if (!workspace || workspaceBytes < need) {
+        mcn_set_error("softmax: workspace %zu < %zu bytes", workspaceBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    MCN_REQUIRE(chunks <= 65535, "softmax: too many outputs");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(divup(numCases, 64), chunks);
+    hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
+    hipLaunchKernelGGL(k_softmax_final, grid, dim3(256), 0, s, x, probs, (const float*)workspace, numOut, numCases, chunks);
+    return MCN_LAUNCH_CHECK("softmax");
+}
+
+// ---------------------------------------------------------------- logreg cost
+// Stage 1: per (case, rowChunk): max prob and how many entries equal it.  Stage 2 (one block):
+// merge chunks, read p[label], write logprob / correctProbs (kLogregCost layer_kernels.cu:59-92)
+// and accumulate the two cost scalars in double.
+__global__ __launch_bounds__(256) void k_logreg_partial(const float* __restrict__ probs, float* __restrict__ part, int numOut, int numCases) {
+    __shared__ float shm[4][64];
+    __shared__ int shc[4][64];
+    const int l = threadIdx.x & 63, col = blockIdx.x * 64 + l, rl = threadIdx.x >> 6, chunk = blockIdx.y;
+    const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
+    float m = -INFINITY;
+    int cnt = 0;
+    if (col < numCases) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float v = probs[(size_t)r * numCases + col];
+            if (v > m) { m = v; cnt = 1; } else if (v == m) cnt++;
+        }
+    }
+    shm[rl][l] = m;
+    shc[rl][l] = cnt;
+    __syncthreads();
+    if (rl == 0 && col < numCases) {
+        for (int k = 1; k < 4; k++) {
+            if (shm[k][l] > m) { m = shm[k][l]; cnt = shc[k][l]; } else if (shm[k][l] == m) cnt += shc[k][l];
+        }
+        part[((size_t)chunk * numCases + col) * 2] = m;
+        part[((size_t)chunk * numCases + col) * 2 + 1] = (float)cnt;
+    }
+}
+__global__ __launch_bounds__(256) void k_logreg_final(const float* __restrict__ labels, const float* __restrict__ probs,
+                                                      const float* __restrict__ part, float* __restrict__ labelLogProbs,
+                                                      float* __restrict__ correctProbs, int numOut, int numCases, int chunks,
+                                                      double* costOut) {
+    __shared__ double sh0[256], sh1[256];
+    double a0 = 0, a1 = 0;
+    for (int col = threadIdx.x; col < numCases; col += 256) {
+        float m = -INFINITY;
+        int cnt = 0;
+        for (int c = 0; c < chunks; c++) {
+            const float pm = part[((size_t)c * numCases + col) * 2];
+            const int pc = (int)part[((size_t)c * numCases + col) * 2 + 1];
+            if (pm > m) { m = pm; cnt = pc; } else if (pm == m) cnt += pc;
+        }
+        const int label = (int)labels[col];
+        const float labelp = probs[(size_t)label * numCases + col];
+        const float lp = logf(labelp);
+        const float cp = labelp != m ? 0.f : 1.0f / (float)cnt;
+        labelLogProbs[col] = lp;
+        correctProbs[col] = cp;
+        a0 += (double)lp;
+        a1 += (double)cp;
+    }
+    sh0[threadIdx.x] = a0;
+    sh1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sh0[threadIdx.x] += sh0[threadIdx.x + o]; sh1[threadIdx.x] += sh1[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && costOut) {
+        costOut[0] += -sh0[0];
+        costOut[1] += (double)numCases - sh1[0];
+    }
+}
+MCN_API size_t mcn_logreg_cost_workspace_bytes(int numOut, int numCases) { return mcn_softmax_workspace_bytes(numOut, numCases); }
+MCN_API int mcn_logreg_cost(const float* labels, const float* probs, float* labelLogProbs, float* correctProbs, int numOut,
+                            int numCases, double* costOut, void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(labels && probs && labelLogProbs && correctProbs && numOut > 0 && numCases > 0, "logregCost: bad argument");
+    const int chunks = divup(numOut, SM_ROWS);
+    const size_t need = mcn_logreg_cost_workspace_bytes(numOut, numCases);
+    if (!workspace || workspaceBytes < need) {
+        mcn_set_error("logregCost: workspace %zu < %zu bytes", workspaceBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_logreg_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, probs, (float*)workspace, numOut, numCases);
+    hipLaunchKernelGGL(k_logreg_final, dim3(1), dim3(256), 0, s, labels, probs, (const float*)workspace, labelLogProbs, correctProbs,
+                       numOut, numCases, chunks, costOut);
+    return MCN_LAUNCH_CHECK("logregCost");
+}
+
+// dx[k,n] (+)= coeff*((label_n == k) - p[k,n])        (kLogregSoftmaxGrad layer_kernels.cu:154-170)
+template <int MODE>  // 0: logreg-softmax grad, 1: logreg grad coeff*(label==k)/p
+__global__ __launch_bounds__(256) void k_logreg_grads(const float* __restrict__ labels, const float* __restrict__ probs,
+                                                      float* __restrict__ target, int numOut, int numCases, int add, float coeff) {
+    const size_t n = (size_t)numOut * numCases;
+    GRID_STRIDE(i, n) {
+        const int k = (int)(i / numCases), c = (int)(i % numCases);
+        const int label = (int)labels[c];
+        const float v = MODE == 0 ? coeff * ((label == k ? 1.f : 0.f) - probs[i]) : coeff * (label == k ? 1.f : 0.f) / probs[i];
+        target[i] = add ? target[i] + v : v;
+    }
+}
+MCN_API int mcn_logreg_softmax_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
+                                    float coeff, void* stream) {
+    MCN_REQUIRE(labels && probs && target && numOut > 0 && numCases > 0, "logregSoftmaxGrad: bad argument");
+    hipLaunchKernelGGL((k_logreg_grads<0>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
+                       target, numOut, numCases, add, coeff);
+    return MCN_LAUNCH_CHECK("logregSoftmaxGrad");
+}
+MCN_API int mcn_logreg_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
+                            float coeff, void* stream) {
+    MCN_REQUIRE(labels && probs && target && numOut > 0 && numCases > 0, "logregGrad: bad argument");
+    hipLaunchKernelGGL((k_logreg_grads<1>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
+                       target, numOut, numCases, add, coeff);
+    return MCN_LAUNCH_CHECK("logregGrad");
+}
+// kSoftmaxGrad (layer_kernels.cu:126-145): O(K) per element, as in the reference (not on the configs' path)
+__global__ __launch_bounds__(256) void k_softmax_grad(const float* __restrict__ acts, const float* __restrict__ g, float* __restrict__ target,
+                                                      int numOut, int numCases, int add) {
+    const size_t n = (size_t)numOut * numCases;
+    GRID_STRIDE(i, n) {
+        const int k = (int)(i / numCases), c = (int)(i % numCases);
+        float v = 0.f;
+        for (int j = 0; j < numOut; j++) v += g[(size_t)j * numCases + c] * ((j == k ? 1.f : 0.f) - acts[(size_t)j * numCases + c]);
+        v *= acts[i];
+        target[i] = add ? target[i] + v : v;
+    }
+}
+MCN_API int mcn_softmax_grad(const float* acts, const float* actsGrad, float* target, int numOut, int numCases, int add, void* stream) {
+    MCN_REQUIRE(acts && actsGrad && target && numOut > 0 && numCases > 0, "softmaxGrad: bad argument");
+    hipLaunchKernelGGL(k_softmax_grad, dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, acts, actsGrad,
+                       target, numOut, numCases, add);
+    return MCN_LAUNCH_CHECK("softmaxGrad");
+}
+
+// ---------------------------------------------------------------- L2-SN (Joint identification-verification)
+// One workgroup.  Phase 1: thread j < N/2 computes label s_j and d_j = sqrt(sum_k (g-p)^2) + 1e-8 with the
+// squares rounded separately and added in row order, exactly the order of the reference's
+// SquaredDiff + column-sum (layer_kernels.cu:554-561, kDumbAggCols) and of the CPU oracle, so the
+// data-dependent margin and every 1[d<m] decision agree bit for bit.  Phase 2: getOptimalThr
+// (:482-498) as an O(h) scan per candidate, first strict maximum wins.  Phase 3: cost or gradient.
+#define L2SN_MAX_PAIRS 4096
+__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs) {
+    const int h = numCases / 2;
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        labs[j] = idens[j] == idens[j + h] ? 1.f : -1.f;
+        float s = 0.f;
+        const float* g = data + j;
+        const float* q = data + j + h;
+#pragma unroll 8
+        for (int k = 0; k < numD; k++) {
+            const float d = g[(size_t)k * numCases] - q[(size_t)k * numCases];
+            s = __fadd_rn(s, __fmul_rn(d, d));
+        }
+        dists[j] = __fadd_rn(sqrtf(s), 0.00000001f);
+    }
+}
+// returns (m, idx) in sh_m[0..1]; candidates/labels of length cnt
+__device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* rates, float* sh_m) {
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const float curr = cd[i];
+        int rate = 0;
+        for (int j = 0; j < cnt; j++) rate += ((cd[j] < curr && cl[j] == 1.f) || (cd[j] > curr && cl[j] == -1.f)) ? 1 : 0;
+        rates[i] = rate;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0, idx = 0;
+        for (int i = 0; i < cnt; i++)
+            if (rates[i] > best) { best = rates[i]; idx = i; }
+        sh_m[0] = cd[idx];
+        sh_m[1] = (float)idx;
+    }
+    __syncthreads();
+}
+template <int MODE>  // 0 cost, 1 grad, 2 stats only
+__global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, const float* __restrict__ data, float* __restrict__ out,
+                                              int numD, int numCases, float m, int add, float coeff, float* info, float* pairStats,
+                                              double* costOut, const float* extD, const float* extL, int extCount) {
+    extern __shared__ float shf[];
+    const int h = numCases / 2;
+    const int cnt = extD ? extCount : h;
+    float* dists = shf;              // [h]
+    float* labs = shf + h;           // [h]
+    float* cd = labs + h;            // [cnt] candidates when external
+    float* cl = cd + (extD ? cnt : 0);
+    int* rates = (int*)(cl + (extD ? cnt : 0));  // [cnt]
+    __shared__ float sh_m[2];
+    __shared__ double shsum[256];
+    l2sn_stats(idens, data, numD, numCases, dists, labs);
+    if (extD) {
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) { cd[i] = extD[i]; cl[i] = extL[i]; }
+    }
+    __syncthreads();
+    if (pairStats) {
+        for (int j = threadIdx.x; j < h; j += blockDim.x) { pairStats[j] = dists[j]; pairStats[h + j] = labs[j]; }
+    }
+    if (MODE == 2) return;
+    float idx = -1.f;
+    if (m < 0) {
+        l2sn_threshold(extD ? cd : dists, extD ? cl : labs, cnt, rates, sh_m);
+        m = sh_m[0];
+        idx = sh_m[1];
+    }
+    if (info && threadIdx.x == 0) { info[0] = m; info[1] = idx; info[2] = 0.f; info[3] = 0.f; }
+    if (MODE == 0) {
+        double a = 0;
+        for (int j = threadIdx.x; j < h; j += blockDim.x) {
+            const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
+            const float negMask2 = dists[j] < m ? 1.f : 0.f;
+            const float posLoss = __fmul_rn(__fmul_rn(__fmul_rn(dists[j], dists[j]), 0.5f), posMask);
+            const float t = __fadd_rn(__fmul_rn(-1.0f, dists[j]), m);
+            const float negLoss = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(t, t), 0.5f), negMask1), negMask2);
+            const float o = __fadd_rn(posLoss, negLoss);
+            out[j] = o;
+            a += (double)o;
+        }
+        shsum[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) shsum[threadIdx.x] += shsum[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && costOut) *costOut += shsum[0];
+    } else {
+        const size_t total = (size_t)numD * h;
+        for (size_t e = threadIdx.x; e < total; e += blockDim.x) {
+            const int k = (int)(e / h), j = (int)(e % h);
+            const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
+            const float negMask2 = dists[j] < m ? 1.f : 0.f;
+            const float r = __fadd_rn(__fmul_rn(1.0f / dists[j], m), -1.0f);
+            const float s1 = data[(size_t)k * numCases + j], s2 = data[(size_t)k * numCases + j + h];
+            const float diff1 = s1 - s2, diff2 = s2 - s1;
+            const float gx = __fadd_rn(__fmul_rn(diff2, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff1, r), negMask1), negMask2));
+            const float gy = __fadd_rn(__fmul_rn(diff1, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff2, r), negMask1), negMask2));
+            float* tg = out + (size_t)k * numCases + j;
+            float* tp = tg + h;
+            *tg = add ? __fadd_rn(*tg, __fmul_rn(gx, coeff)) : __fmul_rn(gx, coeff);
+            *tp = add ? __fadd_rn(*tp, __fmul_rn(gy, coeff)) : __fmul_rn(gy, coeff);
+        }
+    }
+}
+static int l2sn_launch(int mode, const float* idens, const float* data, float* out, int numD, int numCases, float m, int add,
+                       float coeff, float* info, float* pairStats, double* costOut, const float* extD, const float* extL,
+                       int extCount, void* stream) {
+    MCN_REQUIRE(idens && data && (out || mode == 2) && numD > 0 && numCases > 0, "l2sn: bad argument");
+    MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");  // layer_kernels.cu:511
+    MCN_REQUIRE((extD == nullptr) == (extL == nullptr), "l2sn: extDists and extLabels go together");
+    const int h = numCases / 2, cnt = extD ? extCount : h;
+    MCN_REQUIRE(h <= L2SN_MAX_PAIRS && cnt <= L2SN_MAX_PAIRS && cnt > 0, "l2sn: too many pairs (%d)", cnt);
+    const size_t lds = (size_t)(2 * h + (extD ? 2 * cnt : 0) + cnt) * 4;
+    hipStream_t s = (hipStream_t)stream;
+#define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount
+    if (mode == 0) hipLaunchKernelGGL((k_l2sn<0>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+    else if (mode == 1) hipLaunchKernelGGL((k_l2sn<1>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+    else hipLaunchKernelGGL((k_l2sn<2>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+#undef L2SN_ARGS
+    return MCN_LAUNCH_CHECK("l2sn");
+}
+MCN_API int mcn_l2sn_cost(const float* idens, const float* data, float* output, int numD, int numCases, float m, float* info,
+                          float* pairStats, double* costOut, const float* extDists, const float* extLabels, int extCount, void* stream) {
+    return l2sn_launch(0, idens, data, output, numD, numCases, m, 0, 0.f, info, pairStats, costOut, extDists, extLabels, extCount, stream);
+}
+MCN_API int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarget, int numD, int numCases, float m, int add,
+                          float coeff, const float* extDists, const float* extLabels, int extCount, void* stream) {
+    return l2sn_launch(1, idens, data, dataTarget, numD, numCases, m, add, coeff, nullptr, nullptr, nullptr, extDists, extLabels, extCount, stream);
+}
+MCN_API int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream) {
+    MCN_REQUIRE(pairStats, "l2snPairStats: null pointer");
+    return l2sn_launch(2, idens, data, nullptr, numD, numCases, 1.f, 0, 0.f, nullptr, pairStats, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// ---------------------------------------------------------------- L2 regression (attribute towers)
+__global__ __launch_bounds__(256) void k_l2reg_cost(const float* __restrict__ ground, const float* __restrict__ data, float* __restrict__ out,
+                                                    int numD, int numCases, double* costOut) {
+    __shared__ double sh[256];
+    double a = 0;
+    for (int n = threadIdx.x; n < numCases; n += 256) {
+        float s = 0.f;
+        for (int k = 0; k < numD; k++) {
+            const float d = data[(size_t)k * numCases + n] - ground[(size_t)k * numCases + n];
+            s += d * d;
+        }
+        out[n] = s;
+        a += (double)s;
+    }
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && costOut) *costOut += sh[0];
+}
+MCN_API int mcn_l2reg_cost(const float* ground, const float* data, float* output, int numD, int numCases, double* costOut, void* stream) {
+    MCN_REQUIRE(ground && data && output && numD > 0 && numCases > 0, "l2regCost: bad argument");
+    hipLaunchKernelGGL(k_l2reg_cost, dim3(1), dim3(256), 0, (hipStream_t)stream, ground, data, output, numD, numCases, costOut);
+    return MCN_LAUNCH_CHECK("l2regCost");
+}
+__global__ __launch_bounds__(256) void k_l2reg_grad(const float* ground, const float* data, float* target, size_t n, int add, float coeff) {
+    GRID_STRIDE(i, n) {
+        const float v = (ground[i] - data[i]) * coeff;
+        target[i] = add ? target[i] + v : v;
+    }
+}
+MCN_API int mcn_l2reg_grad(const float* ground, const float* data, float* target, int numD, int numCases, int add, float coeff, void* stream) {
+    MCN_REQUIRE(ground && data && target && numD > 0 && numCases > 0, "l2regGrad: bad argument");
+    const size_t n = (size_t)numD * numCases;
+    hipLaunchKernelGGL(k_l2reg_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, ground, data, target, n, add, coeff);
+    return MCN_LAUNCH_CHECK("l2regGrad");
+}
+
+// ---------------------------------------------------------------- SGD (weights.cuh:150-163) in one pass
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ W, float* __restrict__ inc, const float* __restrict__ grad, size_t n,
+                                             float mom, float wcEps, int useGrad, int useWc) {
+    GRID_STRIDE(i, n) {
+        float v = inc[i];
+        const float w = W[i];
+        if (useGrad) v = mom * v + 1.f * grad[i];
+        if (useWc) v = 1.f * v + wcEps * w;
+        inc[i] = v;
+        W[i] = w + v;
+    }
+}
+__global__ __launch_bounds__(256) void k_sgd4(f32x4* __restrict__ W, f32x4* __restrict__ inc, const f32x4* __restrict__ grad, size_t n4,
+                                              float mom, float wcEps, int useGrad, int useWc) {
+    GRID_STRIDE(i, n4) {
+        f32x4 v = inc[i];
+        const f32x4 w = W[i];
+        if (useGrad) v = mom * v + grad[i];
+        if (useWc) v = v + wcEps * w;
+        inc[i] = v;
+        W[i] = w + v;
+    }
+}
+MCN_API int mcn_sgd_update(float* W, float* inc, const float* grad, size_t n, float mom, float wc, float eps, int useGrad, void* stream) {
+    MCN_REQUIRE(W && inc && (!useGrad || grad), "sgdUpdate: null pointer");
+    if (n == 0) return MCN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const float wcEps = -wc * eps;
+    if (n % 4 == 0 && al16(W) && al16(inc) && (!useGrad || al16(grad)))
+        hipLaunchKernelGGL(k_sgd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (f32x4*)W, (f32x4*)inc, (const f32x4*)grad, n / 4, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_sgd, dim3(ew_blocks(n)), dim3(256), 0, s, W, inc, grad, n, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
+    return MCN_LAUNCH_CHECK("sgdUpdate");
+}

@@ -1,0 +1,161 @@
+// Runtime entry points of the C ABI: device / memory / stream / event plumbing
+// and the lazily loaded RCCL communicator (include/mi_convnet.h).
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void mcn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mcn_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return MCN_OK;
+    mcn_set_error("%s: %s", what, hipGetErrorString(e));
+    return MCN_EHIP;
+}
+
+MCN_API const char* mcn_last_error(void) { return g_err; }
+
+MCN_API int mcn_device_count(int* count) { return mcn_check_hip(hipGetDeviceCount(count), "hipGetDeviceCount"); }
+MCN_API int mcn_set_device(int device) { return mcn_check_hip(hipSetDevice(device), "hipSetDevice"); }
+MCN_API int mcn_alloc(void** ptr, size_t bytes) { return mcn_check_hip(hipMalloc(ptr, bytes ? bytes : 4), "hipMalloc"); }
+MCN_API int mcn_free(void* ptr) { return mcn_check_hip(hipFree(ptr), "hipFree"); }
+MCN_API int mcn_host_alloc(void** ptr, size_t bytes) { return mcn_check_hip(hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocDefault), "hipHostMalloc"); }
+MCN_API int mcn_host_free(void* ptr) { return mcn_check_hip(hipHostFree(ptr), "hipHostFree"); }
+MCN_API int mcn_memset(void* ptr, int value, size_t bytes, void* stream) {
+    return mcn_check_hip(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream), "hipMemsetAsync");
+}
+MCN_API int mcn_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    return mcn_check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream), "hipMemcpyAsync(h2d)");
+}
+MCN_API int mcn_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    return mcn_check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync(d2h)");
+}
+MCN_API int mcn_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    return mcn_check_hip(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(d2d)");
+}
+MCN_API int mcn_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                       int kind, void* stream) {
+    hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    return mcn_check_hip(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, (hipStream_t)stream), "hipMemcpy2DAsync");
+}
+MCN_API int mcn_stream_create(void** stream) {
+    hipStream_t s;
+    int rc = mcn_check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    *stream = (void*)s;
+    return rc;
+}
+MCN_API int mcn_stream_destroy(void* stream) { return mcn_check_hip(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
+MCN_API int mcn_stream_sync(void* stream) { return mcn_check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"); }
+MCN_API int mcn_device_sync(void) { return mcn_check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize"); }
+MCN_API int mcn_event_create(void** event) {
+    hipEvent_t e;
+    int rc = mcn_check_hip(hipEventCreate(&e), "hipEventCreate");
+    *event = (void*)e;
+    return rc;
+}
+MCN_API int mcn_event_destroy(void* event) { return mcn_check_hip(hipEventDestroy((hipEvent_t)event), "hipEventDestroy"); }
+MCN_API int mcn_event_record(void* event, void* stream) {
+    return mcn_check_hip(hipEventRecord((hipEvent_t)event, (hipStream_t)stream), "hipEventRecord");
+}
+MCN_API int mcn_event_sync(void* event) { return mcn_check_hip(hipEventSynchronize((hipEvent_t)event), "hipEventSynchronize"); }
+MCN_API int mcn_stream_wait_event(void* stream, void* event) {
+    return mcn_check_hip(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0), "hipStreamWaitEvent");
+}
+MCN_API int mcn_event_elapsed_ms(float* ms, void* start, void* stop) {
+    return mcn_check_hip(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "hipEventElapsedTime");
+}
+
+// ---------------------------------------------------------------------------
+// RCCL, loaded on first use so that single-GPU users never pay for it.
+// Only the five entry points below are bound (signatures from rccl.h).
+// ---------------------------------------------------------------------------
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void* rcclComm_t;
+static struct {
+    void* handle;
+    int (*GetUniqueId)(rcclUniqueId*);
+    int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int);
+    int (*CommDestroy)(rcclComm_t);
+    int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
+    int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
+    const char* (*GetErrorString)(int);
+} g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.handle) return MCN_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        mcn_set_error("cannot load RCCL: %s", dlerror());
+        return MCN_ERCCL;
+    }
+#define BIND(field, sym)                                        \
+    *(void**)(&g_rccl.field) = dlsym(h, sym);                   \
+    if (!g_rccl.field) {                                        \
+        mcn_set_error("RCCL symbol %s missing", sym);           \
+        return MCN_ERCCL;                                       \
+    }
+    BIND(GetUniqueId, "ncclGetUniqueId");
+    BIND(CommInitRank, "ncclCommInitRank");
+    BIND(CommDestroy, "ncclCommDestroy");
+    BIND(AllReduce, "ncclAllReduce");
+    BIND(AllGather, "ncclAllGather");
+    BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+    g_rccl.handle = h;
+    return MCN_OK;
+}
+
+static int rccl_check(int rc, const char* what) {
+    if (rc == 0) return MCN_OK;
+    mcn_set_error("%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return MCN_ERCCL;
+}
+
+MCN_API int mcn_comm_unique_id(char idBytes[128]) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    rcclUniqueId id;
+    rc = rccl_check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+    if (rc) return rc;
+    memcpy(idBytes, id.internal, 128);
+    return MCN_OK;
+}
+
+MCN_API int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    rcclUniqueId id;
+    memcpy(id.internal, idBytes, 128);
+    rcclComm_t c = nullptr;
+    rc = rccl_check(g_rccl.CommInitRank(&c, numRanks, id, rank), "ncclCommInitRank");
+    *comm = c;
+    return rc;
+}
+
+MCN_API int mcn_comm_destroy(void* comm) {
+    if (!g_rccl.handle) return MCN_OK;
+    return rccl_check(g_rccl.CommDestroy((rcclComm_t)comm), "ncclCommDestroy");
+}
+
+// ncclFloat32 = 7, ncclSum = 0 (rccl.h enums)
+MCN_API int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream) {
+    MCN_REQUIRE(g_rccl.handle && comm, "mcn_allreduce_sum: communicator not initialised");
+    return rccl_check(g_rccl.AllReduce(buf, buf, count, 7, 0, (rcclComm_t)comm, (hipStream_t)stream), "ncclAllReduce");
+}
+
+MCN_API int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream) {
+    MCN_REQUIRE(g_rccl.handle && comm, "mcn_allgather: communicator not initialised");
+    return rccl_check(g_rccl.AllGather(send, recv, countPerRank, 7, (rcclComm_t)comm, (hipStream_t)stream), "ncclAllGather");
+}

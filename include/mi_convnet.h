@@ -1,0 +1,272 @@
+/*
+ * mi_convnet.h -- C ABI of the MI355X (gfx950) conv-net compute core.
+ *
+ * This is the drop-in boundary between a cuda-convnet style layer graph and the
+ * HIP kernels: one entry point per public function of the reference's kernel
+ * headers (include/cudaconv2/cudaconv2.cuh, include/cudaconv2/conv_util.cuh,
+ * include/layer_kernels.cuh), the NVMatrix verbs the layers use
+ * (include/nvmatrix/nvmatrix.cuh) and the SGD update of include/weights.cuh.
+ * Every entry cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C: raw device pointers, explicit dimensions, a stream handle
+ *    (hipStream_t passed as void*; NULL = the default stream).  No torch types.
+ *  - every function returns 0 on success, a negative MCN_E* code otherwise and
+ *    never aborts; mcn_last_error() returns a message for the calling thread.
+ *  - no hidden allocation: routines that need scratch take (workspace,
+ *    workspaceBytes) and have a *_workspace_bytes() companion.
+ *  - layouts are the reference's: activations are row-major
+ *    (channels*rows*cols, numImages), images contiguous; conv filters
+ *    (filterChannels*filterPixels, numFilters); local (unshared) filters
+ *    (modules*filterChannels*filterPixels, numFilters)  (filter_acts.cu:39-43).
+ *  - all data is fp32; labels are fp32-encoded integers (layer_kernels.cu:64).
+ *  - unlike the reference (square only: layer.py:351-354) every spatial routine
+ *    takes Y and X sizes separately.
+ *  - "targets = scaleTargets*targets + scaleOutput*result"; scaleTargets == 0
+ *    means targets is write-only (never read, may hold NaNs).
+ */
+#ifndef MI_CONVNET_H
+#define MI_CONVNET_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCN_OK 0
+#define MCN_EINVAL (-1)   /* bad argument / unsupported shape            */
+#define MCN_EHIP (-2)     /* a HIP runtime call failed                   */
+#define MCN_EWORKSPACE (-3) /* workspace too small                       */
+#define MCN_ERCCL (-4)    /* RCCL missing or a collective failed         */
+
+/* neuron types, neuron.cu:32-75 (makeNeuron) */
+enum mcn_neuron {
+    MCN_NEURON_IDENT = 0, MCN_NEURON_RELU = 1, MCN_NEURON_LOGISTIC = 2, MCN_NEURON_BRELU = 3,
+    MCN_NEURON_ABS = 4, MCN_NEURON_TANH = 5, MCN_NEURON_SOFTRELU = 6, MCN_NEURON_SQUARE = 7,
+    MCN_NEURON_SQRT = 8, MCN_NEURON_LINEAR = 9
+};
+
+/* ---- runtime (replaces cudaSetDevice/cublasAlloc/cublasSetMatrix... nvmatrix.cu:60-170, convnet.cu:139-145) */
+const char* mcn_last_error(void);
+int mcn_device_count(int* count);
+int mcn_set_device(int device);
+int mcn_alloc(void** ptr, size_t bytes);
+int mcn_free(void* ptr);
+int mcn_host_alloc(void** ptr, size_t bytes);          /* pinned host memory */
+int mcn_host_free(void* ptr);
+int mcn_memset(void* ptr, int value, size_t bytes, void* stream);
+int mcn_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int mcn_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int mcn_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* kind: 0 h2d, 1 d2h, 2 d2d.  Column-slice copies (data.cu:72-98 sliceCols). */
+int mcn_copy2d(void* dst, size_t dpitchBytes, const void* src, size_t spitchBytes, size_t widthBytes,
+               size_t height, int kind, void* stream);
+int mcn_stream_create(void** stream);
+int mcn_stream_destroy(void* stream);
+int mcn_stream_sync(void* stream);
+int mcn_device_sync(void);
+int mcn_event_create(void** event);
+int mcn_event_destroy(void* event);
+int mcn_event_record(void* event, void* stream);
+int mcn_event_sync(void* event);
+int mcn_stream_wait_event(void* stream, void* event);
+int mcn_event_elapsed_ms(float* ms, void* start, void* stop);
+
+/* ---- cudaconv2.cuh:36-78 ------------------------------------------------------------------ */
+/* convFilterActs (cudaconv2.cuh:39-42, filter_acts.cu:1188-1193) / localFilterActs (:47-50, :1201-1206).
+ * images (numImgColors*imgSizeY*imgSizeX, numImages) with row stride imgStride (>= numImages);
+ * targets (numFilters*numModulesY*numModulesX, numImages).  paddingStart <= 0. */
+int mcn_conv_filter_acts(const float* images, const float* filters, float* targets,
+                         int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                         int numFilters, int filterSize, int numModulesY, int numModulesX,
+                         int paddingStart, int moduleStride, int numGroups,
+                         float scaleTargets, float scaleOutput, void* stream);
+int mcn_local_filter_acts(const float* images, const float* filters, float* targets,
+                          int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                          int numFilters, int filterSize, int numModulesY, int numModulesX,
+                          int paddingStart, int moduleStride, int numGroups,
+                          float scaleTargets, float scaleOutput, void* stream);
+/* Fused forward used by the layer graph: filterActs, then (+ biases) and the
+ * neuron in the epilogue (ConvLayer::fpropActs layer.cu:443-462 + NeuronLayer
+ * layer.cu:249 when the neuron shares the conv's activity matrix).  biases may
+ * be NULL; biasPerModule = 0: one bias per filter (sharedBiases), 1: one per
+ * (filter, module).  Requires scaleTargets == 0 semantics (targets write-only). */
+int mcn_filter_acts_bias_neuron(const float* images, const float* filters, const float* biases, float* targets,
+                                int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                int paddingStart, int moduleStride, int numGroups, int conv,
+                                int biasPerModule, int neuron, float neuronA, float neuronB, void* stream);
+
+/* convImgActs (cudaconv2.cuh:54-56, img_acts.cu:1892-1900) / localImgActs (:60-62, :1904-1912).
+ * hidActs (numFilters*modules, numImages) -> targets (numImgColors*imgSizeY*imgSizeX, numImages). */
+int mcn_conv_img_acts(const float* hidActs, const float* filters, float* targets,
+                      int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                      int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                      int numGroups, float scaleTargets, float scaleOutput, void* stream);
+int mcn_local_img_acts(const float* hidActs, const float* filters, float* targets,
+                       int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                       int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                       int numGroups, float scaleTargets, float scaleOutput, void* stream);
+
+/* convWeightActs (cudaconv2.cuh:67-70, weight_acts.cu:955-964): targets
+ * ((modules/partialSum)*filterChannels*filterPixels, numFilters); partialSum <= 0 means all modules.
+ * localWeightActs (cudaconv2.cuh:76-78, weight_acts.cu:966-976): targets
+ * (modules*filterChannels*filterPixels, numFilters). */
+int mcn_conv_weight_acts(const float* images, const float* hidActs, float* targets,
+                         int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                         int numFilters, int filterSize, int numModulesY, int numModulesX,
+                         int paddingStart, int moduleStride, int numGroups, int partialSum,
+                         float scaleTargets, float scaleOutput, void* stream);
+int mcn_local_weight_acts(const float* images, const float* hidActs, float* targets,
+                          int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                          int numFilters, int filterSize, int numModulesY, int numModulesX,
+                          int paddingStart, int moduleStride, int numGroups,
+                          float scaleTargets, float scaleOutput, void* stream);
+/* ConvLayer::bpropWeights (layer.cu:476-496) in one call: weight gradient summed
+ * over ALL modules, grad = scaleTargets*grad + scaleOutput*sum.  Replaces the
+ * reference's (modules/partialSum) x weights temporary + addSum with a private
+ * module split and a fixed-order second pass over `workspace`. */
+size_t mcn_conv_weight_acts_reduced_workspace_bytes(int numImgColors, int numFilters, int filterSize,
+                                                    int numModulesY, int numModulesX, int numGroups);
+int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, float* grad,
+                                 void* workspace, size_t workspaceBytes,
+                                 int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                 int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                 int paddingStart, int moduleStride, int numGroups,
+                                 float scaleTargets, float scaleOutput, void* stream);
+
+/* ---- conv_util.cuh ---------------------------------------------------------------------- */
+/* convLocalPool<MaxPooler|AvgPooler> (conv_util.cuh:327-517). mode 0 = max, 1 = avg (clipped window). */
+int mcn_local_pool(const float* images, float* target, int numImages, int numFilters, int imgSizeY,
+                   int imgSizeX, int subsX, int startX, int strideX, int outputsY, int outputsX, int mode,
+                   void* stream);
+/* convLocalMaxUndo (conv_util.cuh:40-41, conv_util.cu:1869-1958) */
+int mcn_local_max_undo(const float* images, const float* maxGrads, const float* maxActs, float* target,
+                       int numImages, int numFilters, int imgSizeY, int imgSizeX, int subsX, int startX,
+                       int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput,
+                       void* stream);
+/* convLocalMaxUndo followed by the gradient of the neuron that produced `images`
+ * in place (NeuronLayer::bpropActs layer.cu:245 with actsGradTarget sharing):
+ * target = neuronGrad(maxUndo(...), images).  Only neurons whose gradient needs
+ * their output alone (ident, relu, brelu, logistic, tanh, sqrt, linear). */
+int mcn_local_max_undo_neuron(const float* images, const float* maxGrads, const float* maxActs, float* target,
+                              int numImages, int numFilters, int imgSizeY, int imgSizeX, int subsX, int startX,
+                              int strideX, int outputsY, int outputsX, int neuron, float neuronA, float neuronB,
+                              void* stream);
+/* convLocalAvgUndo (conv_util.cuh:37-39, conv_util.cu:1968-2062) */
+int mcn_local_avg_undo(const float* avgGrads, float* target, int numImages, int numFilters, int imgSizeY,
+                       int imgSizeX, int subsX, int startX, int strideX, int outputsY, int outputsX,
+                       float scaleTargets, float scaleOutput, void* stream);
+/* convResponseNorm (conv_util.cuh:43, conv_util.cu:2064-2072) */
+int mcn_response_norm(const float* images, float* denoms, float* target, int numImages, int numFilters,
+                      int imgSizeY, int imgSizeX, int sizeX, float addScale, float powScale, void* stream);
+/* convResponseNormUndo (conv_util.cuh:44-45, conv_util.cu:2228-2412). OVERWRITES acts. */
+int mcn_response_norm_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,
+                           float* target, int numImages, int numFilters, int imgSizeY, int imgSizeX, int sizeX,
+                           float addScale, float powScale, float scaleTargets, float scaleOutput, void* stream);
+/* convResponseNormCrossMap (conv_util.cuh:69-70, conv_util.cu:2892-2894) */
+int mcn_response_norm_cross_map(const float* images, float* denoms, float* target, int numImages,
+                                int numFilters, int imgPixels, int sizeF, float addScale, float powScale,
+                                int blocked, void* stream);
+/* convResponseNormCrossMapUndo (conv_util.cuh:67-68, conv_util.cu:2801-2890). OVERWRITES acts. */
+int mcn_response_norm_cross_map_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,
+                                     float* target, int numImages, int numFilters, int imgPixels, int sizeF,
+                                     float addScale, float powScale, int blocked, float scaleTargets,
+                                     float scaleOutput, void* stream);
+
+/* ---- neuron.cuh ----------------------------------------------------------------------------- */
+/* Neuron::activate (neuron.cuh:87-92); in-place allowed (out == in). */
+int mcn_neuron_fwd(const float* in, float* out, size_t numElements, int neuron, float a, float b, void* stream);
+/* Neuron::computeInputGrad (neuron.cuh:94-102): target = (add ? target : 0) + grad.  `acts` = neuron
+ * output, `inputs` = neuron input (only read by abs / square).  target may alias actsGrad. */
+int mcn_neuron_bwd(const float* actsGrad, const float* acts, const float* inputs, float* target,
+                   size_t numElements, int neuron, float a, float b, int add, void* stream);
+
+/* ---- NVMatrix verbs (nvmatrix.cuh:60-456) -------------------------------------------------- */
+/* addProduct / rightMult (nvmatrix.cu:189-239, cublasSgemm).  Row-major
+ * C[MxN] = beta*C + alpha*op(A)*op(B); transA: A is stored [KxM]; transB: B is stored [NxK]. */
+size_t mcn_gemm_workspace_bytes(int M, int N, int K, int transA, int transB);
+int mcn_gemm(const float* A, const float* B, float* C, int M, int N, int K, int transA, int transB,
+             float alpha, float beta, void* workspace, size_t workspaceBytes, void* stream);
+/* FCLayer::fpropActs (layer.cu:355-360) in one call: C = A*B (+ bias[row]) then neuron.  bias may be NULL. */
+int mcn_gemm_bias_neuron(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                         float beta, int neuron, float neuronA, float neuronB,
+                         void* workspace, size_t workspaceBytes, void* stream);
+/* addVector (nvmatrix.cu:652-690): mat(rows x cols) += scale*vec; perRow=1: vec[rows], 0: vec[cols]. */
+int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream);
+/* addSum (nvmatrix.cu:896-906 -> _aggregate :700-805): tgt = scaleThis*tgt + scaleSum*sum(mat, axis).
+ * axis 1: row sums (tgt[rows]); axis 0: column sums (tgt[cols]). */
+size_t mcn_add_sum_workspace_bytes(int rows, int cols, int axis);
+int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int axis, float scaleThis, float scaleSum,
+                void* workspace, size_t workspaceBytes, void* stream);
+/* NVMatrix::add (nvmatrix.cuh eltwise WeightedAdd): a = sa*a + sb*b */
+int mcn_axpby(float* a, const float* b, size_t n, float sa, float sb, void* stream);
+/* NVMatrix::scale / copy with scale: out = s*in */
+int mcn_scale(const float* in, float* out, size_t n, float s, void* stream);
+/* eltwise max (EltwiseMaxLayer layer.cu:643-649): out = max(a, b) */
+int mcn_eltwise_max(const float* a, const float* b, float* out, size_t n, void* stream);
+/* computeEltwiseMaxGrad (layer_kernels.cuh, layer_kernels.cu:172-204) */
+int mcn_eltwise_max_grad(const float* actGrad, const float* input, const float* output, float* target,
+                         size_t n, int add, void* stream);
+/* NVMatrix::sum() (nvmatrix.cu:936-979): *out (device double) = sum; accumulate != 0 adds to *out. */
+int mcn_sum_all(const float* a, size_t n, double* outDevice, int accumulate, void* stream);
+/* NVMatrix::transpose (hard transpose, worker.cu:201-208): dst (cols x rows) = src(rows x cols)^T */
+int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream);
+
+/* ---- layer_kernels.cuh:39-56 and SoftmaxLayer (layer.cu:585-595) ---------------------------- */
+size_t mcn_softmax_workspace_bytes(int numOut, int numCases);
+int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes,
+                void* stream);
+/* computeLogregCost (layer_kernels.cuh:39, layer_kernels.cu:216-239) + the two NVMatrix::sum() of
+ * LogregCostLayer::fpropActs (layer.cu:978-979): costOut[0] += -sum(logprob), costOut[1] += numCases - sum(correct)
+ * (device doubles; pass NULL to skip). */
+size_t mcn_logreg_cost_workspace_bytes(int numOut, int numCases);
+int mcn_logreg_cost(const float* labels, const float* probs, float* labelLogProbs, float* correctProbs,
+                    int numOut, int numCases, double* costOut, void* workspace, size_t workspaceBytes, void* stream);
+/* computeLogregGrad (layer_kernels.cu:241-263) */
+int mcn_logreg_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
+                    float coeff, void* stream);
+/* computeSoftmaxGrad (layer_kernels.cu:265-285) */
+int mcn_softmax_grad(const float* acts, const float* actsGrad, float* target, int numOut, int numCases, int add,
+                     void* stream);
+/* computeLogregSoftmaxGrad (layer_kernels.cu:287-308) */
+int mcn_logreg_softmax_grad(const float* labels, const float* probs, float* target, int numOut, int numCases,
+                            int add, float coeff, void* stream);
+/* computeL2SNCost (layer_kernels.cu:505-604) incl. getOptimalThr (:482-498) run on the device.
+ * output[numCases/2]; info (device, 4 floats, may be NULL): {m used, index of chosen pair or -1, 0, 0};
+ * pairStats (device, 2*numCases/2 floats, may be NULL): dists then pair labels;
+ * costOut (device double, may be NULL): += sum(output).
+ * Multi-GPU: when extDists/extLabels (device, extCount entries each) are given the margin is searched
+ * over those (the all-gathered pairs of every rank) instead of the local pairs. */
+int mcn_l2sn_cost(const float* idens, const float* data, float* output, int numD, int numCases, float m,
+                  float* info, float* pairStats, double* costOut,
+                  const float* extDists, const float* extLabels, int extCount, void* stream);
+/* computeL2SNGrad (layer_kernels.cu:620-735): dataTarget (numD, numCases) (+)= coeff * grad */
+int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarget, int numD, int numCases, float m,
+                  int add, float coeff, const float* extDists, const float* extLabels, int extCount, void* stream);
+/* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2] */
+int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream);
+/* computeL2regCost / computeL2regGrad (layer_kernels.cu:744-794) */
+int mcn_l2reg_cost(const float* ground, const float* data, float* output, int numD, int numCases,
+                   double* costOut, void* stream);
+int mcn_l2reg_grad(const float* ground, const float* data, float* target, int numD, int numCases, int add,
+                   float coeff, void* stream);
+
+/* ---- weights.cuh:150-163 --------------------------------------------------------------------- */
+/* Weights::update in one pass: useGrad: inc = mom*inc + grad; wc>0: inc -= wc*eps*W; W += inc. */
+int mcn_sgd_update(float* W, float* inc, const float* grad, size_t n, float mom, float wc, float eps,
+                   int useGrad, void* stream);
+
+/* ---- data-parallel exchange (no counterpart in the reference, which is single-GPU: convnet.py:52-53).
+ * RCCL is loaded lazily; one communicator per process (one process per GPU). */
+int mcn_comm_unique_id(char idBytes[128]);
+int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]);
+int mcn_comm_destroy(void* comm);
+int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream);
+int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_CONVNET_H */

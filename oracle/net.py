@@ -1,0 +1,582 @@
+"""TEST INFRASTRUCTURE ONLY: whole-net CPU oracle.
+
+Restates the reference's layer-graph orchestration (Layer::fprop/bprop
+layer.cu:75-158, WeightLayer :258-343, FCLayer :350-384, ConvLayer :438-521,
+LocalUnsharedLayer :527-575, SoftmaxLayer :582-607, pool :685-736, norm
+:847-885, cost layers :920-1116, ConvNet::fprop/bprop/updateWeights
+convnet.cu:190-245, TrainingWorker::run worker.cu:88-102, Weights::update
+weights.cuh:150-163) over numpy arrays, calling the C oracle kernels.
+
+It is deliberately independent of the product's C++ layer graph so that the
+two can be compared.  All activation matrices are held in the reference's
+memory layout, (features, numCases) row-major; the FC "soft transpose"
+(layer.cu:98-101) is folded into the GEMM orientation.
+
+PARITY UNPINNED (see convnet_oracle.cpp header); tests/test_oracle_pins.py
+holds the soft pins (grad-check < 0.02, log shapes, ln K first cost).
+"""
+import numpy as np
+
+from . import oracle as K
+
+PASS_TRAIN, PASS_TEST, PASS_GC = 0, 1, 2
+
+
+class Weights:
+    """weights.cuh:41-198 (no weight sharing: 'next' scope)."""
+
+    def __init__(self, w, inc, eps, wc, mom, use_grad, fortran):
+        # host arrays keep the caller's layout; `W`/`inc` below are the flat memory images
+        self.hW, self.hInc = w, inc
+        self.fortran = fortran
+        self.W = self._mem(w).copy()
+        self.inc = self._mem(inc).copy()
+        self.grad = np.zeros_like(self.W) if use_grad else None
+        self.eps, self.wc, self.mom, self.use_grad = eps, wc, mom, use_grad
+        self.num_updates = 0
+
+    def _mem(self, a):
+        return np.ascontiguousarray(a.T) if self.fortran else np.ascontiguousarray(a)
+
+    def get_grad(self):
+        return self.grad if self.use_grad else self.inc
+
+    def update(self):
+        if self.eps > 0:
+            K.sgd_update(self.W, self.inc, self.grad, self.mom, self.wc, self.eps, self.use_grad)
+            self.num_updates = 0
+
+    def copy_to_host(self):
+        self.hW[...] = self.W.T if self.fortran else self.W
+        self.hInc[...] = self.inc.T if self.fortran else self.inc
+
+
+class Layer:
+    def __init__(self, net, d):
+        self.net, self.d = net, d
+        self.name, self.type = d['name'], d['type']
+        self.outputs = d['outputs']
+        self.grad_consumer = bool(d['gradConsumer'])
+        self.acts_target, self.acts_grad_target = d['actsTarget'], d['actsGradTarget']
+        self.prev, self.next = [], []
+        self.num_grad_producers_next = 0
+        self._found = False
+        self.acts = None
+        self._acts_grad = None
+        self.rcvd_f = self.rcvd_b = 0
+
+    # -- graph ---------------------------------------------------------
+    def is_grad_consumer(self):
+        if not self._found:
+            for p in self.prev:
+                self.grad_consumer |= p.is_grad_consumer()
+            self._found = True
+        return self.grad_consumer
+
+    def is_grad_producer(self):
+        return True
+
+    def get_acts_grad(self):
+        if self.acts_grad_target >= 0:
+            return self.prev[self.acts_grad_target].get_acts_grad()
+        n = self.net.num_cases
+        if self._acts_grad is None or self._acts_grad.shape != (self.outputs, n):
+            self._acts_grad = np.zeros((self.outputs, n), np.float32)
+        return self._acts_grad
+
+    def reset(self):
+        self.rcvd_f = self.rcvd_b = 0
+
+    # -- forward (layer.cu:75-114) --------------------------------------
+    def fprop_one(self, pt):
+        self.rcvd_f += 1
+        if self.rcvd_f == len(self.prev):
+            self.fprop([p.acts for p in self.prev], pt)
+
+    def fprop(self, inputs, pt):
+        self.inputs = inputs
+        n = self.net.num_cases
+        if self.acts_target >= 0:
+            self.acts = inputs[self.acts_target]
+        elif self.acts is None or self.acts.shape != (self.outputs, n) or any(self.acts is i for i in inputs):
+            self.acts = np.zeros((self.outputs, n), np.float32)
+        self.rcvd_f = len(self.prev)
+        if self.acts_target >= 0:
+            self.fprop_acts(self.acts_target, 0, pt)
+        for i in range(len(self.prev)):
+            if i != self.acts_target:
+                self.fprop_acts(i, 1 if (self.acts_target >= 0 or i > 0) else 0, pt)
+        for nx in self.next:
+            nx.fprop_one(pt)
+
+    # -- backward (layer.cu:116-158) ------------------------------------
+    def bprop(self, pt):
+        if self.rcvd_b == self.num_grad_producers_next:
+            self.rcvd_b += 1
+            self.bprop_v(self.get_acts_grad(), pt)
+
+    def bprop_v(self, v, pt):
+        self.bprop_common(v, pt)
+        if self.is_grad_producer():
+            for i, p in enumerate(self.prev):
+                if p.is_grad_consumer() and self.acts_grad_target != i:
+                    self.bprop_acts(v, i, 1 if p.rcvd_b > 0 else 0, pt)
+                    p.rcvd_b += 1
+            t = self.acts_grad_target
+            if t >= 0 and self.prev[t].is_grad_consumer():
+                self.bprop_acts(v, t, 1 if self.prev[t].rcvd_b > 0 else 0, pt)
+                self.prev[t].rcvd_b += 1
+            for p in self.prev:
+                if p.is_grad_consumer():
+                    p.bprop(pt)
+
+    def bprop_common(self, v, pt):
+        pass
+
+    def fprop_acts(self, i, scale_targets, pt):
+        pass
+
+    def bprop_acts(self, v, i, scale_targets, pt):
+        pass
+
+    def update_weights(self):
+        pass
+
+    def copy_to_host(self):
+        pass
+
+
+class DataLayer(Layer):
+    def is_grad_producer(self):
+        return False
+
+    def fprop_data(self, data, pt):
+        self.acts = data[self.d['dataIdx']]
+        for nx in self.next:
+            nx.fprop_one(pt)
+
+
+class NeuronLayer(Layer):
+    def __init__(self, net, d):
+        super().__init__(net, d)
+        nd = d['neuron']
+        self.ntype = nd['type']
+        self.a = float(nd['params'].get('a', 0.0))
+        self.b = float(nd['params'].get('b', 0.0))
+
+    def fprop_acts(self, i, st, pt):
+        if self.ntype == 'ident' and self.acts is self.inputs[0]:
+            return
+        K.neuron_fwd(self.inputs[0], self.ntype, self.a, self.b, out=self.acts)
+
+    def bprop_acts(self, v, i, st, pt):
+        tgt = self.prev[0].get_acts_grad()
+        if self.ntype == 'ident' and tgt is v:
+            return
+        K.neuron_bwd(v, self.acts, self.inputs[0], self.ntype, self.a, self.b, target=tgt, add=st > 0)
+
+
+class WeightLayer(Layer):
+    def __init__(self, net, d, use_grad, fortran):
+        super().__init__(net, d)
+        assert all(i < 0 for i in d['weightSourceLayerIndices']), 'weight sharing is outside the oracle scope'
+        self.weights = [Weights(w, wi, e, c, m, use_grad, fortran)
+                        for w, wi, e, c, m in zip(d['weights'], d['weightsInc'], d['epsW'], d['wc'], d['momW'])]
+        self.biases = Weights(d['biases'], d['biasesInc'], d['epsB'], 0.0, d['momB'], True, False)
+        # biases are vectors: their memory image is layout independent
+        self.biases.W = np.ascontiguousarray(d['biases']).reshape(-1).copy()
+        self.biases.inc = np.ascontiguousarray(d['biasesInc']).reshape(-1).copy()
+        self.biases.grad = np.zeros_like(self.biases.W)
+        self.w_step, self.b_step = 0.001, 0.002  # layer.cu:294-295
+
+    def bprop_common(self, v, pt):  # layer.cu:306-317
+        if self.biases.eps > 0:
+            self.bprop_biases(v, pt)
+        for i, w in enumerate(self.weights):
+            if w.eps > 0:
+                self.bprop_weights(v, i, pt)
+                w.num_updates += 1
+
+    def update_weights(self):
+        for w in self.weights:
+            w.update()
+        self.biases.update()
+
+    def copy_to_host(self):
+        for w in self.weights:
+            w.copy_to_host()
+        self.d['biases'].reshape(-1)[...] = self.biases.W
+        self.d['biasesInc'].reshape(-1)[...] = self.biases.inc
+
+
+class FCLayer(WeightLayer):
+    def __init__(self, net, d):
+        super().__init__(net, d, False, True)
+        self.w_step, self.b_step = 0.1, 0.01  # layer.cu:351-352
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:355-360
+        n, I = self.net.num_cases, self.prev[i].outputs
+        K.gemm(self.weights[i].W, self.inputs[i], self.outputs, n, I, beta=float(st), Cmat=self.acts)
+        if st == 0:
+            K.add_vector(self.acts, self.biases.W, self.outputs, n, True)
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:362-366
+        n, I = self.net.num_cases, self.prev[i].outputs
+        K.gemm(self.weights[i].W, v, I, n, self.outputs, ta=True, beta=float(st), Cmat=self.prev[i].get_acts_grad())
+
+    def bprop_biases(self, v, pt):  # layer.cu:368-372
+        n = self.net.num_cases
+        sc = 1.0 if pt == PASS_GC else self.biases.eps / n
+        K.add_sum(self.biases.grad, v, self.outputs, n, 1, 0.0, sc)
+
+    def bprop_weights(self, v, i, pt):  # layer.cu:374-384
+        n, I = self.net.num_cases, self.prev[i].outputs
+        w = self.weights[i]
+        scale_inc = (1.0 if (w.num_updates == 0 and pt != PASS_GC) else 0.0) * w.mom
+        scale_grad = 1.0 if pt == PASS_GC else w.eps / n
+        K.gemm(v, self.prev[i].acts, self.outputs, I, n, tb=True, alpha=scale_grad, beta=scale_inc, Cmat=w.inc)
+
+
+class LocalLayer(WeightLayer):
+    def __init__(self, net, d, use_grad, conv):
+        super().__init__(net, d, use_grad, False)
+        self.conv = conv
+
+    def geo(self, i):
+        d = self.d
+        return dict(imgY=d['imgSizeY'][i], imgX=d['imgSizeX'][i], C_=d['channels'][i], F=d['filters'],
+                    fs=d['filterSize'][i], mY=d['modulesY'], mX=d['modulesX'], pad=d['padding'][i],
+                    stride=d['stride'][i], groups=d['groups'][i])
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:443-462, :530-543
+        d, n = self.d, self.net.num_cases
+        K.filter_acts(self.inputs[i], self.weights[i].W, n, targets=self.acts, sT=float(st), sO=1.0,
+                      conv=self.conv, **self.geo(i))
+        if st == 0:
+            if self.conv and d['sharedBiases']:
+                K.add_vector(self.acts, self.biases.W, d['filters'], d['modules'] * n, True)
+            else:
+                K.add_vector(self.acts, self.biases.W, d['filters'] * d['modules'], n, True)
+
+    def bprop_biases(self, v, pt):  # layer.cu:464-474, :545-549
+        d, n = self.d, self.net.num_cases
+        sc = 1.0 if pt == PASS_GC else self.biases.eps / n
+        if self.conv and d['sharedBiases']:
+            K.add_sum(self.biases.grad, v, d['filters'], d['modules'] * n, 1, 0.0, sc)
+        else:
+            K.add_sum(self.biases.grad, v, d['filters'] * d['modules'], n, 1, 0.0, sc)
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:498-513, :566-575
+        K.img_acts(v, self.weights[i].W, self.net.num_cases, targets=self.prev[i].get_acts_grad(),
+                   sT=float(st), sO=1.0, conv=self.conv, **self.geo(i))
+
+
+class ConvLayer(LocalLayer):
+    def __init__(self, net, d):
+        super().__init__(net, d, True, True)
+
+    def bprop_weights(self, v, i, pt):  # layer.cu:476-496
+        d, n = self.d, self.net.num_cases
+        w = self.weights[i]
+        ps = d['partialSum']
+        scale_w = 1.0 if pt == PASS_GC else w.eps / n
+        if ps > 0:
+            tmp = K.weight_acts(self.prev[i].acts, v, n, partial_sum=ps, sT=0.0, sO=scale_w, conv=True, **self.geo(i))
+            rows = d['modules'] // ps
+            K.add_sum(w.grad.reshape(-1), tmp, rows, tmp.size // rows, 0, 1.0 if w.num_updates > 0 else 0.0, 1.0)
+        else:
+            K.weight_acts(self.prev[i].acts, v, n, partial_sum=0, targets=w.grad,
+                          sT=1.0 if w.num_updates > 0 else 0.0, sO=scale_w, conv=True, **self.geo(i))
+
+
+class LocalUnsharedLayer(LocalLayer):
+    def __init__(self, net, d):
+        super().__init__(net, d, False, False)
+
+    def bprop_weights(self, v, i, pt):  # layer.cu:551-564
+        n = self.net.num_cases
+        w = self.weights[i]
+        scale_inc = (1.0 if (pt != PASS_GC and w.num_updates == 0) else 0.0) * w.mom
+        scale_w = 1.0 if pt == PASS_GC else w.eps / n
+        K.weight_acts(self.prev[i].acts, v, n, targets=w.inc, sT=scale_inc, sO=scale_w, conv=False, **self.geo(i))
+
+
+class SoftmaxLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:585-595
+        self.acts[...] = K.softmax(self.inputs[0], self.outputs, self.net.num_cases)
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:597-607
+        n = self.net.num_cases
+        tgt = self.prev[0].get_acts_grad()
+        if len(self.next) == 1 and self.next[0].type == 'cost.logreg':
+            labels = self.next[0].prev[0].acts
+            K.logreg_softmax_grad(labels, self.acts, self.outputs, n, self.next[0].coeff, target=tgt, add=st == 1)
+        else:
+            K.softmax_grad(self.acts, v, self.outputs, n, target=tgt, add=st == 1)
+
+
+class EltwiseSumLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:618-624
+        c = np.float32(self.d['coeffs'][i])
+        if st == 0:
+            self.acts[...] = self.inputs[i] * c
+        else:
+            K.axpby(self.acts, self.inputs[i], 1.0, float(c))
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:626-633
+        c = np.float32(self.d['coeffs'][i])
+        tgt = self.prev[i].get_acts_grad()
+        if st == 0:
+            tgt[...] = v * c
+        else:
+            K.axpby(tgt, v, float(st), float(c))
+
+
+class EltwiseMaxLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:643-649
+        if i == 1:
+            np.maximum(self.inputs[1], self.inputs[0], out=self.acts)
+        elif i > 1:
+            np.maximum(self.acts, self.inputs[i], out=self.acts)
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:651-653, layer_kernels.cu:172-182
+        tgt = self.prev[i].get_acts_grad()
+        g = v * (self.acts == self.inputs[i]).astype(np.float32)
+        if st != 0:
+            tgt += g
+        else:
+            tgt[...] = g
+
+
+class PoolLayer(Layer):
+    def args(self):
+        d = self.d
+        return (self.net.num_cases, d['channels'], d['imgSizeY'], d['imgSizeX'], d['sizeX'], d['start'], d['stride'],
+                d['outputsY'], d['outputsX'])
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:714-716, :730-732
+        self.acts[...] = K.local_pool(self.inputs[0], *self.args(), mode=self.d['pool'])
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:718-720, :734-736
+        tgt = self.prev[0].get_acts_grad()
+        if self.d['pool'] == 'max':
+            K.local_max_undo(self.prev[0].acts, v, self.acts, *self.args(), target=tgt, sT=float(st), sO=1.0)
+        else:
+            K.local_avg_undo(v, *self.args(), target=tgt, sT=float(st), sO=1.0)
+
+
+class ResponseNormLayer(Layer):
+    cross = False
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:855-857, :879-881
+        d, n = self.d, self.net.num_cases
+        if self.cross:
+            t, self.denoms = K.response_norm_cross_map(self.inputs[0], n, d['channels'], d['imgPixels'], d['size'],
+                                                       d['scale'], d['pow'], d['blocked'])
+        else:
+            t, self.denoms = K.response_norm(self.inputs[0], n, d['channels'], d['imgSizeY'], d['imgSizeX'], d['size'],
+                                             d['scale'], d['pow'])
+        self.acts[...] = t
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:859-861, :883-885 (destroys own acts)
+        d, n = self.d, self.net.num_cases
+        tgt = self.prev[0].get_acts_grad()
+        if self.cross:
+            K.response_norm_cross_map_undo(v, self.denoms, self.prev[0].acts, self.acts, n, d['channels'], d['imgPixels'],
+                                           d['size'], d['scale'], d['pow'], d['blocked'], target=tgt, sT=float(st), sO=1.0)
+        else:
+            K.response_norm_undo(v, self.denoms, self.prev[0].acts, self.acts, n, d['channels'], d['imgSizeY'],
+                                 d['imgSizeX'], d['size'], d['scale'], d['pow'], target=tgt, sT=float(st), sO=1.0)
+
+
+class CrossMapResponseNormLayer(ResponseNormLayer):
+    cross = True
+
+
+class CostLayer(Layer):
+    def __init__(self, net, d):
+        super().__init__(net, d)
+        self.coeff = float(d['coeff'])
+        self.costv = []
+
+    def bprop(self, pt):  # layer.cu:929-933
+        if self.coeff != 0:
+            super().bprop(pt)
+
+    def is_grad_producer(self):
+        return self.coeff != 0
+
+
+class LogregCostLayer(CostLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:969-981
+        if i == 0:
+            labels, probs = self.inputs
+            n = self.net.num_cases
+            lp, cp = K.logreg_cost(labels, probs, probs.shape[0], n)
+            self.acts = lp
+            self.costv = [-K.sum_all(lp), n - K.sum_all(cp)]
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:983-994
+        assert i == 1
+        p = self.prev[1]
+        if len(p.next) > 1 or p.type != 'softmax':
+            K.logreg_grad(self.prev[0].acts, p.acts, p.outputs, self.net.num_cases, self.coeff,
+                          target=p.get_acts_grad(), add=st == 1)
+
+
+class SumOfSquaresCostLayer(CostLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:1004-1008
+        self.acts = self.inputs[0] * self.inputs[0]
+        self.costv = [K.sum_all(self.acts)]
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:1010-1012
+        K.axpby(self.prev[i].get_acts_grad(), self.inputs[0], float(st), -2 * self.coeff)
+
+
+class L2SNCostLayer(CostLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:1060-1071
+        if i == 0:
+            labels, data = self.inputs
+            out, self.m_used, self.m_idx, self.dists, self.pair_labels = K.l2sn_cost(
+                labels, data, data.shape[0], self.net.num_cases, self.d['m'])
+            self.acts = out
+            self.costv = [K.sum_all(out)]
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:1073-1082
+        if i == 1:
+            data = self.prev[1].acts
+            K.l2sn_grad(self.prev[0].acts, data, data.shape[0], self.net.num_cases, self.coeff, self.d['m'],
+                        target=self.prev[1].get_acts_grad(), add=st == 1)
+
+
+class L2regCostLayer(CostLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:1093-1105
+        if i == 0:
+            ground, predict = self.inputs
+            out = K.l2reg_cost(np.ascontiguousarray(ground), predict, predict.shape[0], self.net.num_cases)
+            self.acts = out
+            self.costv = [K.sum_all(out)]
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:1107-1116
+        assert i == 1
+        ground, predict = self.inputs
+        K.l2reg_grad(np.ascontiguousarray(ground), predict, predict.shape[0], self.net.num_cases, self.coeff,
+                     target=self.prev[1].get_acts_grad(), add=st == 1)
+
+
+_TYPES = {'fc': FCLayer, 'conv': ConvLayer, 'local': LocalUnsharedLayer, 'pool': PoolLayer,
+          'rnorm': ResponseNormLayer, 'cmrnorm': CrossMapResponseNormLayer, 'softmax': SoftmaxLayer,
+          'eltsum': EltwiseSumLayer, 'eltmax': EltwiseMaxLayer, 'neuron': NeuronLayer, 'data': DataLayer,
+          'cost.logreg': LogregCostLayer, 'cost.sum2': SumOfSquaresCostLayer, 'cost.l2-sn': L2SNCostLayer,
+          'cost.l2-reg': L2regCostLayer}
+
+
+class OracleNet:
+    """ConvNet (convnet.cu:44-81) + TrainingWorker (worker.cu:88-102) on the CPU oracle."""
+
+    def __init__(self, layers, minibatch_size=128):
+        self.minibatch_size = minibatch_size
+        self.layers, self.costs, self.data_layers = [], [], []
+        for d in layers:
+            l = _TYPES[d['type']](self, d)
+            self.layers.append(l)
+            if d['type'] == 'data':
+                self.data_layers.append(l)
+            if d['type'].startswith('cost.'):
+                self.costs.append(l)
+            for i in d.get('inputs', []):
+                l.prev.append(self.layers[i])
+        for l in self.layers:
+            for p in l.prev:
+                p.next.append(l)
+                p.num_grad_producers_next += l.is_grad_producer()
+        self.num_cases = 0
+
+    def layer(self, name):
+        return next(l for l in self.layers if l.name == name)
+
+    def fprop(self, data, pt=PASS_TRAIN):
+        self.num_cases = data[0].shape[1]
+        self.data = data
+        for l in self.layers:
+            l.reset()
+        for dl in self.data_layers:
+            dl.fprop_data(data, pt)
+
+    def bprop(self, pt=PASS_TRAIN):
+        for c in self.costs:
+            c.bprop(pt)
+        for l in self.layers:
+            l.reset()
+
+    def update_weights(self):
+        for l in self.layers:
+            l.update_weights()
+
+    def get_cost(self):
+        return {c.name: list(c.costv) for c in self.costs}
+
+    def cost_value(self):
+        return sum(c.coeff * c.costv[0] for c in self.costs)
+
+    def run_batch(self, data, test=False):
+        """data: list of (dims, numCases) float32 arrays.  Returns ({name: [sums]}, numCases)."""
+        n_total = data[0].shape[1]
+        tot = {}
+        for s in range(0, n_total, self.minibatch_size):
+            mini = [np.ascontiguousarray(d[:, s:s + self.minibatch_size]) for d in data]
+            self.fprop(mini, PASS_TEST if test else PASS_TRAIN)
+            for k, v in self.get_cost().items():
+                acc = tot.setdefault(k, [0.0] * len(v))
+                for j, x in enumerate(v):
+                    acc[j] += x
+            if not test:
+                self.bprop(PASS_TRAIN)
+                self.update_weights()
+        return tot, n_total
+
+    def write_features(self, data, layer_idx):
+        """FeatureWorker::run (worker.cu:191-214): (numCases, features) row-major."""
+        n_total = data[0].shape[1]
+        out = np.empty((n_total, self.layers[layer_idx].outputs), np.float32)
+        for s in range(0, n_total, self.minibatch_size):
+            mini = [np.ascontiguousarray(d[:, s:s + self.minibatch_size]) for d in data]
+            self.fprop(mini, PASS_TEST)
+            out[s:s + mini[0].shape[1]] = self.layers[layer_idx].acts.T
+        return out
+
+    def sync_with_host(self):
+        for l in self.layers:
+            l.copy_to_host()
+
+    # -- the reference's only self-check (convnet.cu:257-330) ---------------
+    def check_gradients(self, data, max_elems=40, seed=0, thresh=0.02):
+        """Finite-difference check with the reference's steps and threshold.
+        Unlike the reference, at most `max_elems` entries of each matrix are
+        perturbed (seeded choice); norms are taken over that subset."""
+        rng = np.random.default_rng(seed)
+        self.fprop(data, PASS_GC)
+        base = self.cost_value()
+        self.bprop(PASS_GC)
+        n = self.num_cases
+        results = []
+        for l in self.layers:
+            if not isinstance(l, WeightLayer):
+                continue
+            mats = [('%s weights[%d]' % (l.name, i), w, l.w_step) for i, w in enumerate(l.weights)]
+            mats.append(('%s biases' % l.name, l.biases, l.b_step))
+            for name, w, eps in mats:
+                flat = w.W.reshape(-1)
+                anal = (w.get_grad().reshape(-1) * (-1.0 / n)).astype(np.float64)
+                idx = rng.choice(flat.size, size=min(max_elems, flat.size), replace=False)
+                num = np.zeros(len(idx))
+                for j, e in enumerate(idx):
+                    v = flat[e]
+                    flat[e] = v + np.float32(eps)
+                    self.fprop(data, PASS_GC)
+                    num[j] = (self.cost_value() - base) / (n * eps)
+                    flat[e] = v
+                an = anal[idx]
+                rel = np.linalg.norm(num - an) / max(np.linalg.norm(an), 1e-30)
+                results.append((name, float(rel), bool(rel < thresh)))
+        return results
