@@ -9,6 +9,13 @@
 #include <algorithm>
 #include "common.h"
 
+// No multiply-add contraction in this file: the reference runs every NVMatrix op of the
+// cost layers as its own kernel (layer_kernels.cu:505-735), so products and sums are rounded
+// separately, and the L2-SN margin / 1[d<m] decisions are discontinuous in the last bit.
+// (HIP's __fmul_rn/__fadd_rn are plain operators and would be fused under the default
+// -ffp-contract=fast.)
+#pragma clang fp contract(off)
+
 #define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
 
 static inline unsigned ew_blocks(size_t n, int per = 256) { return (unsigned)std::min<size_t>(divup_sz(n, per), 16384); }

@@ -1,0 +1,663 @@
+"""GPU parity tests: every C-ABI entry point of include/mi_convnet.h against the CPU
+oracle on the same seeded inputs, at the shapes of the BASELINE configs
+ plus ragged batch sizes (the reference special-cases
+N % 128 / 64 / 32, filter_acts.cu:604-608).
+
+Tolerance (fp32, stated per SURVEY 8d): max|a-b| <= 1e-4*max|b| + 1e-6 per tensor;
+exact agreement for argmax / correctProbs, max-pool routing and L2-SN decisions.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from kutil import call, close, dev, dev_double, dev_empty, ws_bytes, capi
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RAGGED = [1, 33, 64, 96, 128, 130]
+
+# name: (imgY, imgX, C, F, fs, mY, mX, pad, stride, groups, conv)
+GEOMS = {
+    'conv1_55': (55, 55, 3, 16, 4, 52, 52, 0, 1, 1, True),
+    'conv1_39x31': (39, 31, 3, 16, 4, 36, 28, 0, 1, 1, True),
+    'conv1_plus': (55, 55, 3, 32, 4, 52, 52, 0, 1, 1, True),
+    'conv2': (26, 26, 16, 32, 3, 24, 24, 0, 1, 1, True),
+    'conv2_39x31': (18, 14, 16, 32, 3, 16, 12, 0, 1, 1, True),
+    'local3': (12, 12, 32, 48, 3, 10, 10, 0, 1, 1, False),
+    'local3_39x31': (8, 6, 32, 48, 3, 6, 4, 0, 1, 1, False),
+    'local4': (5, 5, 48, 64, 2, 4, 4, 0, 1, 1, False),
+    'local4_39x31': (3, 2, 48, 64, 2, 2, 1, 0, 1, 1, False),
+    'cifar_conv1': (32, 32, 3, 32, 5, 32, 32, -2, 1, 1, True),
+    'cifar_conv2': (16, 16, 32, 32, 5, 16, 16, -2, 1, 1, True),
+    'cifar_conv3': (8, 8, 32, 64, 5, 8, 8, -2, 1, 1, True),
+    'stride2_pad': (13, 11, 8, 16, 3, 7, 6, -1, 2, 1, True),
+    'groups2': (10, 10, 16, 32, 3, 8, 8, 0, 1, 2, True),
+    'local_groups2_pad': (7, 7, 8, 32, 3, 7, 7, -1, 1, 2, False),
+    'odd_k': (9, 9, 1, 16, 3, 7, 7, 0, 1, 1, True),
+}
+
+
+def geo_kw(g):
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    return dict(imgY=imgY, imgX=imgX, C_=C_, F=F, fs=fs, mY=mY, mX=mX, pad=pad, stride=stride, groups=groups)
+
+
+def mk(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def filt_shape(g):
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rows = (C_ // groups) * fs * fs * (1 if conv else mY * mX)
+    return rows, F
+
+
+# ----------------------------------------------------------------------------------- filterActs
+@pytest.mark.parametrize('name', list(GEOMS))
+def test_filter_acts_shapes(name):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(1)
+    img = mk(rng, C_ * imgY * imgX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    want = O.filter_acts(img, W, N, conv=conv, **geo_kw(g))
+    d_img, d_W, d_out = dev(img), dev(W), dev_empty(want.shape, np.nan)
+    call('mcn_conv_filter_acts' if conv else 'mcn_local_filter_acts', d_img, d_W, d_out, N, N, imgY, imgX, C_, F, fs,
+         mY, mX, pad, stride, groups, 0.0, 1.0, None)
+    close(d_out.numpy(), want, what=name)
+
+
+@pytest.mark.parametrize('N', RAGGED)
+@pytest.mark.parametrize('name', ['conv1_39x31', 'conv2_39x31', 'local3', 'cifar_conv3'])
+def test_filter_acts_ragged(name, N):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(2)
+    img = mk(rng, C_ * imgY * imgX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    tgt0 = mk(rng, F * mY * mX, N)
+    want = O.filter_acts(img, W, N, conv=conv, targets=tgt0.copy(), sT=0.5, sO=2.0, **geo_kw(g))
+    d_out = dev(tgt0)
+    call('mcn_conv_filter_acts' if conv else 'mcn_local_filter_acts', dev(img), dev(W), d_out, N, N, imgY, imgX, C_, F,
+         fs, mY, mX, pad, stride, groups, 0.5, 2.0, None)
+    close(d_out.numpy(), want, what='%s N=%d' % (name, N))
+
+
+def test_filter_acts_strided_minibatch():
+    """images as a column slice of a wider data matrix (data.cu:72-98 without the host copy)."""
+    g = GEOMS['conv1_39x31']
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(3)
+    big = mk(rng, C_ * imgY * imgX, 512)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    d_big = dev(big)
+    for start, N in ((128, 128), (384, 128), (256, 100)):
+        sl = np.ascontiguousarray(big[:, start:start + N])
+        want = O.filter_acts(sl, W, N, conv=True, **geo_kw(g))
+        d_out = dev_empty(want.shape, np.nan)
+        call('mcn_conv_filter_acts', d_big.offset(4 * start), dev(W), d_out, N, 512, imgY, imgX, C_, F, fs, mY, mX,
+             pad, stride, groups, 0.0, 1.0, None)
+        close(d_out.numpy(), want, what='slice %d' % start)
+
+
+@pytest.mark.parametrize('name,per_module', [('conv1_39x31', 0), ('conv2', 0), ('local3', 1), ('cifar_conv1', 1)])
+def test_filter_acts_bias_neuron(name, per_module):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N, M = 128, mY * mX
+    rng = np.random.default_rng(4)
+    img = mk(rng, C_ * imgY * imgX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    b = mk(rng, F * M if per_module else F, scale=0.1)
+    want = O.filter_acts(img, W, N, conv=conv, **geo_kw(g))
+    if per_module:
+        O.add_vector(want, b, F * M, N, True)
+    else:
+        O.add_vector(want, b, F, M * N, True)
+    want = O.neuron_fwd(want, 'relu')
+    d_out = dev_empty(want.shape, np.nan)
+    call('mcn_filter_acts_bias_neuron', dev(img), dev(W), dev(b), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride,
+         groups, int(conv), per_module, 1, 0.0, 0.0, None)
+    close(d_out.numpy(), want, what=name)
+
+
+def test_filter_acts_rejects_bad_args():
+    L = capi.lib()
+    d = dev(np.zeros(16, np.float32))
+    rc = L.raw('mcn_conv_filter_acts')(d.ptr, d.ptr, d.ptr, 4, 4, 5, 5, 3, 15, 3, 3, 3, 0, 1, 1, C.c_float(0), C.c_float(1), None)
+    assert rc == -1 and b'numFilters' in L.raw('mcn_last_error')()
+    rc = L.raw('mcn_conv_filter_acts')(d.ptr, d.ptr, d.ptr, 4, 4, 5, 5, 3, 16, 3, 3, 3, 1, 1, 1, C.c_float(0), C.c_float(1), None)
+    assert rc == -1 and b'paddingStart' in L.raw('mcn_last_error')()
+
+
+# ----------------------------------------------------------------------------------- imgActs
+@pytest.mark.parametrize('name', ['conv2', 'conv2_39x31', 'local3', 'local3_39x31', 'local4', 'local4_39x31', 'conv1_39x31',
+                                  'cifar_conv2', 'cifar_conv3', 'stride2_pad', 'groups2', 'local_groups2_pad', 'odd_k'])
+def test_img_acts_shapes(name):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(5)
+    hid = mk(rng, F * mY * mX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    want = O.img_acts(hid, W, N, conv=conv, **geo_kw(g))
+    d_out = dev_empty(want.shape, np.nan)
+    call('mcn_conv_img_acts' if conv else 'mcn_local_img_acts', dev(hid), dev(W), d_out, N, imgY, imgX, C_, F, fs, mY, mX,
+         pad, stride, groups, 0.0, 1.0, None)
+    close(d_out.numpy(), want, what=name)
+
+
+@pytest.mark.parametrize('N', RAGGED)
+@pytest.mark.parametrize('name', ['conv2_39x31', 'local4'])
+def test_img_acts_ragged_accumulate(name, N):
+    """scaleTargets=1: pool3 also receives gradient from fc5 (layer.cu:138)."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(6)
+    hid = mk(rng, F * mY * mX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    t0 = mk(rng, C_ * imgY * imgX, N)
+    want = O.img_acts(hid, W, N, conv=conv, targets=t0.copy(), sT=1.0, sO=1.0, **geo_kw(g))
+    d_out = dev(t0)
+    call('mcn_conv_img_acts' if conv else 'mcn_local_img_acts', dev(hid), dev(W), d_out, N, imgY, imgX, C_, F, fs, mY, mX,
+         pad, stride, groups, 1.0, 1.0, None)
+    close(d_out.numpy(), want, what='%s N=%d' % (name, N))
+
+
+# ----------------------------------------------------------------------------------- weightActs
+@pytest.mark.parametrize('name,ps', [('conv1_55', 1), ('conv1_39x31', 1), ('conv1_39x31', 0), ('conv2', 1), ('conv2_39x31', 4),
+                                     ('cifar_conv1', 32), ('cifar_conv3', 0), ('stride2_pad', 1), ('groups2', 8), ('odd_k', 1),
+                                     ('local3', 1), ('local3_39x31', 1), ('local4', 1), ('local4_39x31', 1),
+                                     ('local_groups2_pad', 1)])
+def test_weight_acts_shapes(name, ps):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(7)
+    img = mk(rng, C_ * imgY * imgX, N)
+    hid = mk(rng, F * mY * mX, N)
+    want = O.weight_acts(img, hid, N, partial_sum=ps, conv=conv, sO=0.01, **geo_kw(g))
+    d_out = dev_empty(want.shape, np.nan)
+    if conv:
+        call('mcn_conv_weight_acts', dev(img), dev(hid), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, ps,
+             0.0, 0.01, None)
+    else:
+        call('mcn_local_weight_acts', dev(img), dev(hid), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups,
+             0.0, 0.01, None)
+    close(d_out.numpy(), want, what=name)
+
+
+@pytest.mark.parametrize('N', RAGGED)
+@pytest.mark.parametrize('name', ['conv2_39x31', 'local3_39x31'])
+def test_weight_acts_ragged_momentum(name, N):
+    """local layers write inc = mom*inc + (eps/N)*g directly (layer.cu:551-564)."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(8)
+    img = mk(rng, C_ * imgY * imgX, N)
+    hid = mk(rng, F * mY * mX, N)
+    rows = (C_ // groups) * fs * fs * mY * mX
+    t0 = mk(rng, rows, F, scale=0.01)
+    want = O.weight_acts(img, hid, N, partial_sum=1, conv=conv, targets=t0.copy(), sT=0.9, sO=5e-4 / N, **geo_kw(g))
+    d_out = dev(t0)
+    fn = 'mcn_conv_weight_acts' if conv else 'mcn_local_weight_acts'
+    args = [dev(img), dev(hid), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups]
+    if conv:
+        args.append(1)
+    call(fn, *args, 0.9, 5e-4 / N, None)
+    close(d_out.numpy(), want, what='%s N=%d' % (name, N))
+
+
+@pytest.mark.parametrize('name', ['conv1_55', 'conv1_39x31', 'conv2', 'conv2_39x31', 'cifar_conv1', 'cifar_conv3'])
+@pytest.mark.parametrize('sT', [0.0, 1.0])
+def test_conv_weight_acts_reduced(name, sT):
+    """ConvLayer::bpropWeights in one call == weightActs(partialSum) + addSum over module chunks."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(9)
+    img = mk(rng, C_ * imgY * imgX, N)
+    hid = mk(rng, F * mY * mX, N)
+    K = (C_ // groups) * fs * fs
+    g0 = mk(rng, K, F, scale=0.01)
+    tmp = O.weight_acts(img, hid, N, partial_sum=1, conv=True, sO=5e-4 / N, **geo_kw(g))
+    want = g0.copy().reshape(-1)
+    O.add_sum(want, tmp, mY * mX, K * F, 0, sT, 1.0)
+    nbytes = ws_bytes('mcn_conv_weight_acts_reduced_workspace_bytes', C_, F, fs, mY, mX, groups)
+    wsb = capi.workspace(nbytes)
+    d_out = dev(g0)
+    call('mcn_conv_weight_acts_reduced', dev(img), dev(hid), d_out, wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad,
+         stride, groups, sT, 5e-4 / N, None)
+    close(d_out.numpy(), want.reshape(K, F), what=name)
+
+
+# ----------------------------------------------------------------------------------- pooling
+POOLS = {  # F, imgY, imgX, size, start, stride, outY, outX
+    'pool1': (16, 52, 52, 2, 0, 2, 26, 26),
+    'pool1_39x31': (16, 36, 28, 2, 0, 2, 18, 14),
+    'pool2': (32, 24, 24, 2, 0, 2, 12, 12),
+    'pool3': (48, 10, 10, 2, 0, 2, 5, 5),
+    'pool3_39x31': (48, 6, 4, 2, 0, 2, 3, 2),
+    'cifar_3_2': (32, 32, 32, 3, 0, 2, 16, 16),
+    'odd_clip': (16, 7, 9, 3, -1, 2, 4, 5),
+}
+
+
+@pytest.mark.parametrize('mode', ['max', 'avg'])
+@pytest.mark.parametrize('name', list(POOLS))
+@pytest.mark.parametrize('N', [128, 33])
+def test_local_pool(name, mode, N):
+    F, imgY, imgX, size, start, stride, outY, outX = POOLS[name]
+    rng = np.random.default_rng(10)
+    img = mk(rng, F * imgY * imgX, N)
+    want = O.local_pool(img, N, F, imgY, imgX, size, start, stride, outY, outX, mode)
+    d_out = dev_empty(want.shape, np.nan)
+    call('mcn_local_pool', dev(img), d_out, N, F, imgY, imgX, size, start, stride, outY, outX, 0 if mode == 'max' else 1, None)
+    got = d_out.numpy()
+    if mode == 'max':
+        assert np.array_equal(got, want), name  # pure selection: bit exact
+    else:
+        close(got, want, what=name)
+
+
+@pytest.mark.parametrize('name', list(POOLS))
+@pytest.mark.parametrize('N,sT', [(128, 0.0), (130, 1.0)])
+def test_local_max_undo(name, N, sT):
+    F, imgY, imgX, size, start, stride, outY, outX = POOLS[name]
+    rng = np.random.default_rng(11)
+    # relu'd inputs: plenty of ties at 0 -> exercises "every pixel equal to the max gets the gradient"
+    img = np.maximum(mk(rng, F * imgY * imgX, N), 0)
+    acts = O.local_pool(img, N, F, imgY, imgX, size, start, stride, outY, outX, 'max')
+    grads = mk(rng, *acts.shape)
+    t0 = mk(rng, *img.shape)
+    want = O.local_max_undo(img, grads, acts, N, F, imgY, imgX, size, start, stride, outY, outX, target=t0.copy(), sT=sT, sO=1.0)
+    d_out = dev(t0)
+    call('mcn_local_max_undo', dev(img), dev(grads), dev(acts), d_out, N, F, imgY, imgX, size, start, stride, outY, outX,
+         sT, 1.0, None)
+    got = d_out.numpy()
+    assert np.array_equal(got != 0, want != 0), 'max-pool gradient routing differs'
+    close(got, want, what=name)
+
+
+@pytest.mark.parametrize('name', ['pool1_39x31', 'pool3', 'cifar_3_2'])
+def test_local_max_undo_neuron(name):
+    F, imgY, imgX, size, start, stride, outY, outX = POOLS[name]
+    N = 128
+    rng = np.random.default_rng(12)
+    img = np.maximum(mk(rng, F * imgY * imgX, N), 0)
+    acts = O.local_pool(img, N, F, imgY, imgX, size, start, stride, outY, outX, 'max')
+    grads = mk(rng, *acts.shape)
+    undo = O.local_max_undo(img, grads, acts, N, F, imgY, imgX, size, start, stride, outY, outX)
+    want = O.neuron_bwd(undo, img, img, 'relu')
+    d_out = dev_empty(img.shape, np.nan)
+    call('mcn_local_max_undo_neuron', dev(img), dev(grads), dev(acts), d_out, N, F, imgY, imgX, size, start, stride, outY,
+         outX, 1, 0.0, 0.0, None)
+    close(d_out.numpy(), want, what=name)
+
+
+@pytest.mark.parametrize('name', ['pool2', 'cifar_3_2', 'odd_clip'])
+@pytest.mark.parametrize('N,sT', [(128, 0.0), (33, 1.0)])
+def test_local_avg_undo(name, N, sT):
+    F, imgY, imgX, size, start, stride, outY, outX = POOLS[name]
+    rng = np.random.default_rng(13)
+    grads = mk(rng, F * outY * outX, N)
+    t0 = mk(rng, F * imgY * imgX, N)
+    want = O.local_avg_undo(grads, N, F, imgY, imgX, size, start, stride, outY, outX, target=t0.copy(), sT=sT, sO=1.0)
+    d_out = dev(t0)
+    call('mcn_local_avg_undo', dev(grads), d_out, N, F, imgY, imgX, size, start, stride, outY, outX, sT, 1.0, None)
+    close(d_out.numpy(), want, what=name)
+
+
+# ----------------------------------------------------------------------------------- response normalisation
+@pytest.mark.parametrize('F,imgY,imgX,size', [(32, 16, 16, 3), (16, 9, 7, 5), (32, 8, 8, 9)])
+@pytest.mark.parametrize('N', [128, 33])
+def test_response_norm_fwd_bwd(F, imgY, imgX, size, N):
+    rng = np.random.default_rng(14)
+    x = mk(rng, F * imgY * imgX, N)
+    scale, pw = 0.001 / size ** 2 * 50, 0.75
+    want, wden = O.response_norm(x, N, F, imgY, imgX, size, scale, pw)
+    d_x, d_den, d_y = dev(x), dev_empty(x.shape, np.nan), dev_empty(x.shape, np.nan)
+    call('mcn_response_norm', d_x, d_den, d_y, N, F, imgY, imgX, size, scale, pw, None)
+    close(d_den.numpy(), wden, what='denoms')
+    close(d_y.numpy(), want, what='rnorm')
+    og = mk(rng, *x.shape)
+    t0 = mk(rng, *x.shape)
+    acts = want.copy()
+    wt = O.response_norm_undo(og, wden, x, acts, N, F, imgY, imgX, size, scale, pw, target=t0.copy(), sT=1.0, sO=1.0)
+    d_acts, d_t = dev(want), dev(t0)
+    call('mcn_response_norm_undo', dev(og), dev(wden), d_x, d_acts, d_t, N, F, imgY, imgX, size, scale, pw, 1.0, 1.0, None)
+    close(d_acts.numpy(), acts, what='rnorm undo: overwritten acts')
+    close(d_t.numpy(), wt, what='rnorm undo')
+
+
+@pytest.mark.parametrize('F,px,size,blocked', [(32, 64, 9, 0), (64, 16, 5, 0), (32, 30, 4, 1), (16, 25, 16, 0)])
+@pytest.mark.parametrize('N', [128, 33])
+def test_response_norm_cross_map_fwd_bwd(F, px, size, blocked, N):
+    rng = np.random.default_rng(15)
+    x = mk(rng, F * px, N)
+    scale, pw = 0.001 / size * 50, 0.75
+    want, wden = O.response_norm_cross_map(x, N, F, px, size, scale, pw, blocked)
+    d_x, d_den, d_y = dev(x), dev_empty(x.shape, np.nan), dev_empty(x.shape, np.nan)
+    call('mcn_response_norm_cross_map', d_x, d_den, d_y, N, F, px, size, scale, pw, blocked, None)
+    close(d_den.numpy(), wden, what='denoms')
+    close(d_y.numpy(), want, what='cmrnorm')
+    og = mk(rng, *x.shape)
+    acts = want.copy()
+    wt = O.response_norm_cross_map_undo(og, wden, x, acts, N, F, px, size, scale, pw, blocked)
+    d_acts, d_t = dev(want), dev_empty(x.shape, np.nan)
+    call('mcn_response_norm_cross_map_undo', dev(og), dev(wden), d_x, d_acts, d_t, N, F, px, size, scale, pw, blocked,
+         0.0, 1.0, None)
+    close(d_t.numpy(), wt, what='cmrnorm undo')
+
+
+# ----------------------------------------------------------------------------------- neurons
+NEURON_CASES = [('ident', 0, 0), ('relu', 0, 0), ('logistic', 0, 0), ('brelu', 1.5, 0), ('abs', 0, 0), ('tanh', 1.7159, 0.6667),
+                ('softrelu', 0, 0), ('square', 0, 0), ('sqrt', 0, 0), ('linear', 2.0, -0.5)]
+
+
+@pytest.mark.parametrize('ntype,a,b', NEURON_CASES)
+@pytest.mark.parametrize('n', [128 * 97, 1001])
+def test_neurons(ntype, a, b, n):
+    rng = np.random.default_rng(16)
+    x = mk(rng, n, scale=2.0)
+    if ntype == 'sqrt':
+        x = np.abs(x) + 0.1
+    tid = O.NEURON_TYPES[ntype]
+    want = O.neuron_fwd(x, ntype, a, b)
+    d_x, d_y = dev(x), dev_empty(x.shape, np.nan)
+    call('mcn_neuron_fwd', d_x, d_y, n, tid, a, b, None)
+    close(d_y.numpy(), want, rtol=2e-6, what=ntype)
+    g = mk(rng, n)
+    for add in (0, 1):
+        t0 = mk(rng, n)
+        wg = O.neuron_bwd(g, want, x, ntype, a, b, target=t0.copy(), add=bool(add))
+        d_t = dev(t0)
+        call('mcn_neuron_bwd', dev(g), dev(want), d_x, d_t, n, tid, a, b, add, None)
+        close(d_t.numpy(), wg, rtol=1e-5, what=ntype + ' grad')
+
+
+def test_relu_in_place():
+    rng = np.random.default_rng(17)
+    x = mk(rng, 4800, 128)
+    d = dev(x)
+    call('mcn_neuron_fwd', d, d, x.size, 1, 0.0, 0.0, None)
+    assert np.array_equal(d.numpy(), np.maximum(x, 0))
+
+
+# ----------------------------------------------------------------------------------- GEMM (FC layers)
+FC_SHAPES = [(160, 1024), (160, 1200), (4213, 160), (10575, 160), (512, 2048), (10, 1024), (27, 160), (2, 160)]
+
+
+@pytest.mark.parametrize('O_,I', FC_SHAPES)
+@pytest.mark.parametrize('N', [128, 33])
+def test_fc_gemms(O_, I, N):
+    rng = np.random.default_rng(18)
+    W = mk(rng, O_, I, scale=0.01)      # Fortran-order (I, O) host matrix == [O][I] in memory (layer.py:788)
+    X = mk(rng, I, N)
+    dY = mk(rng, O_, N)
+    b = mk(rng, O_, scale=0.1)
+    L = capi.lib()
+
+    def run(A, B, Cmat, M, Nn, K, ta, tb, alpha, beta):
+        nb = ws_bytes('mcn_gemm_workspace_bytes', M, Nn, K, ta, tb)
+        wsb = capi.workspace(nb)
+        d_c = dev(Cmat)
+        call('mcn_gemm', dev(A), dev(B), d_c, M, Nn, K, ta, tb, alpha, beta, wsb, nb, None)
+        return d_c.numpy()
+
+    # fwd (layer.cu:355-360)
+    y0 = mk(rng, O_, N)
+    want = O.gemm(W, X, O_, N, I, beta=1.0, Cmat=y0.copy())
+    close(run(W, X, y0, O_, N, I, 0, 0, 1.0, 1.0), want, what='fwd')
+    # fused fwd + bias (+relu)
+    want = O.gemm(W, X, O_, N, I)
+    O.add_vector(want, b, O_, N, True)
+    want = O.neuron_fwd(want, 'relu')
+    nb = ws_bytes('mcn_gemm_workspace_bytes', O_, N, I, 0, 0)
+    wsb = capi.workspace(nb)
+    d_c = dev_empty((O_, N), np.nan)
+    call('mcn_gemm_bias_neuron', dev(W), dev(X), dev(b), d_c, O_, N, I, 0.0, 1, 0.0, 0.0, wsb, nb, None)
+    close(d_c.numpy(), want, what='fwd+bias+relu')
+    # bwd-data (layer.cu:362-366)
+    dx0 = mk(rng, I, N)
+    want = O.gemm(W, dY, I, N, O_, ta=True, beta=1.0, Cmat=dx0.copy())
+    close(run(W, dY, dx0, I, N, O_, 1, 0, 1.0, 1.0), want, what='bwd-data')
+    # bwd-weights into inc with momentum (layer.cu:374-384)
+    inc0 = mk(rng, O_, I, scale=0.01)
+    want = O.gemm(dY, X, O_, I, N, tb=True, alpha=5e-4 / N, beta=0.9, Cmat=inc0.copy())
+    close(run(dY, X, inc0, O_, I, N, 0, 1, 5e-4 / N, 0.9), want, what='bwd-weights')
+
+
+def test_gemm_odd_sizes():
+    rng = np.random.default_rng(19)
+    for M, N, K, ta, tb in [(37, 45, 51, 0, 0), (37, 45, 51, 1, 0), (37, 45, 51, 0, 1), (1, 1, 1, 0, 0), (300, 130, 2049, 0, 0)]:
+        A = mk(rng, *((K, M) if ta else (M, K)))
+        B = mk(rng, *((N, K) if tb else (K, N)))
+        want = O.gemm(A, B, M, N, K, ta=bool(ta), tb=bool(tb), alpha=0.5)
+        nb = ws_bytes('mcn_gemm_workspace_bytes', M, N, K, ta, tb)
+        wsb = capi.workspace(nb)
+        d_c = dev_empty((M, N), np.nan)
+        call('mcn_gemm', dev(A), dev(B), d_c, M, N, K, ta, tb, 0.5, 0.0, wsb, nb, None)
+        close(d_c.numpy(), want, what=str((M, N, K, ta, tb)))
+
+
+# ----------------------------------------------------------------------------------- NVMatrix verbs
+@pytest.mark.parametrize('rows,cols', [(16, 36 * 28 * 128), (16, 52 * 52 * 128), (4800, 128), (10575, 128), (160, 33), (3, 100000)])
+def test_add_vector_and_add_sum(rows, cols):
+    rng = np.random.default_rng(20)
+    mat = mk(rng, rows, cols)
+    for per_row in (1, 0):
+        vec = mk(rng, rows if per_row else cols)
+        want = O.add_vector(mat.copy(), vec, rows, cols, bool(per_row), 0.5)
+        d = dev(mat)
+        call('mcn_add_vector', d, dev(vec), rows, cols, per_row, 0.5, None)
+        close(d.numpy(), want, what='addVector')
+    for axis in (1, 0):
+        n_out = rows if axis == 1 else cols
+        t0 = mk(rng, n_out)
+        for sthis in (0.0, 0.9):
+            want = O.add_sum(t0.copy(), mat, rows, cols, axis, sthis, 5e-4 / 128)
+            nb = ws_bytes('mcn_add_sum_workspace_bytes', rows, cols, axis)
+            wsb = capi.workspace(nb)
+            d_t = dev(t0)
+            call('mcn_add_sum', d_t, dev(mat), rows, cols, axis, sthis, 5e-4 / 128, wsb, nb, None)
+            # long fp32 sums: error grows with sqrt(len); tolerance relative to the sum of |terms|
+            bound = 2e-6 * np.abs(mat).sum(axis=axis).max() * 5e-4 / 128 + 1e-9
+            assert np.max(np.abs(d_t.numpy().astype(np.float64) - want)) <= max(bound, 1e-4 * np.abs(want).max() + 1e-6)
+
+
+def test_eltwise_verbs():
+    rng = np.random.default_rng(21)
+    for n in (128 * 1200, 1003):
+        a, b, g = mk(rng, n), mk(rng, n), mk(rng, n)
+        d_a = dev(a)
+        call('mcn_axpby', d_a, dev(b), n, 0.9, -0.25, None)
+        close(d_a.numpy(), O.axpby(a.copy(), b, 0.9, -0.25), what='axpby')
+        d_o = dev_empty(n, np.nan)
+        call('mcn_scale', dev(a), d_o, n, 1.5, None)
+        close(d_o.numpy(), a * np.float32(1.5), what='scale')
+        call('mcn_eltwise_max', dev(a), dev(b), d_o, n, None)
+        mx = np.maximum(a, b)
+        assert np.array_equal(d_o.numpy(), mx)
+        t0 = mk(rng, n)
+        d_t = dev(t0)
+        call('mcn_eltwise_max_grad', dev(g), dev(a), dev(mx), d_t, n, 1, None)
+        close(d_t.numpy(), t0 + g * (mx == a), what='eltmax grad')
+        d_s = dev_double(1)
+        call('mcn_sum_all', dev(a), n, d_s, 0, None)
+        call('mcn_sum_all', dev(b), n, d_s, 1, None)
+        got = d_s.numpy()[0]
+        assert abs(got - (O.sum_all(a) + O.sum_all(b))) <= 1e-9 * np.abs(a).sum() + 1e-9
+
+
+@pytest.mark.parametrize('rows,cols', [(160, 128), (10575, 33), (31, 77)])
+def test_transpose(rows, cols):
+    rng = np.random.default_rng(22)
+    a = mk(rng, rows, cols)
+    d_o = dev_empty((cols, rows), np.nan)
+    call('mcn_transpose', dev(a), d_o, rows, cols, None)
+    assert np.array_equal(d_o.numpy(), a.T)
+
+
+# ----------------------------------------------------------------------------------- softmax / logreg
+@pytest.mark.parametrize('K', [10575, 4213, 4131, 10, 257])
+@pytest.mark.parametrize('N', [128, 33, 1])
+def test_softmax_logreg(K, N):
+    rng = np.random.default_rng(23)
+    x = mk(rng, K, N, scale=3.0)
+    labels = rng.integers(0, K, size=(1, N)).astype(np.float32)
+    want = O.softmax(x, K, N)
+    nb = ws_bytes('mcn_softmax_workspace_bytes', K, N)
+    wsb = capi.workspace(nb)
+    d_p = dev_empty((K, N), np.nan)
+    call('mcn_softmax', dev(x), d_p, K, N, wsb, nb, None)
+    got = d_p.numpy()
+    close(got, want, what='softmax')
+    assert np.array_equal(got.argmax(0), want.argmax(0))
+    np.testing.assert_allclose(got.sum(0), 1.0, atol=5e-5)
+
+    # cost on the ORACLE's probabilities so that tie decisions see identical inputs
+    probs = want.copy()
+    if N > 4:  # force ties and label==argmax cases (layer_kernels.cu:82-90)
+        k0 = int(labels[0, 0])
+        probs[:, 0] = 0.0
+        probs[k0, 0] = 0.5
+        probs[(k0 + 1) % K, 0] = 0.5
+        k1 = int(labels[0, 1])
+        probs[:, 1] = 1e-3
+        probs[k1, 1] = 0.9
+        probs[:, 2] = 1.0 / K  # all tied
+    wlp, wcp = O.logreg_cost(labels, probs, K, N)
+    nb = ws_bytes('mcn_logreg_cost_workspace_bytes', K, N)
+    wsb = capi.workspace(nb)
+    d_lp, d_cp, d_cost = dev_empty((1, N), np.nan), dev_empty((1, N), np.nan), dev_double(2)
+    call('mcn_logreg_cost', dev(labels), dev(probs), d_lp, d_cp, K, N, d_cost, wsb, nb, None)
+    assert np.array_equal(d_cp.numpy(), wcp), 'correctProbs must agree exactly'
+    close(d_lp.numpy(), wlp, rtol=2e-6, what='logprob')
+    cost = d_cost.numpy()
+    assert abs(cost[0] + O.sum_all(wlp)) <= 1e-5 * abs(O.sum_all(wlp)) + 1e-6
+    assert abs(cost[1] - (N - O.sum_all(wcp))) <= 1e-6
+
+    for add in (0, 1):
+        t0 = mk(rng, K, N)
+        wg = O.logreg_softmax_grad(labels, probs, K, N, 1.0, target=t0.copy(), add=bool(add))
+        d_t = dev(t0)
+        call('mcn_logreg_softmax_grad', dev(labels), dev(probs), d_t, K, N, add, 1.0, None)
+        close(d_t.numpy(), wg, what='logreg-softmax grad')
+    wg = O.logreg_grad(labels, want, K, N, 0.5)
+    d_t = dev_empty((K, N), np.nan)
+    call('mcn_logreg_grad', dev(labels), dev(want), d_t, K, N, 0, 0.5, None)
+    close(d_t.numpy(), wg, rtol=1e-5, what='logreg grad')
+
+
+def test_softmax_grad_small():
+    rng = np.random.default_rng(24)
+    K, N = 37, 33
+    acts = O.softmax(mk(rng, K, N), K, N)
+    g = mk(rng, K, N)
+    want = O.softmax_grad(acts, g, K, N)
+    d_t = dev_empty((K, N), np.nan)
+    call('mcn_softmax_grad', dev(acts), dev(g), d_t, K, N, 0, None)
+    close(d_t.numpy(), want, rtol=1e-4, atol=1e-6, what='softmax grad')
+
+
+# ----------------------------------------------------------------------------------- L2-SN (Joint identification-verification)
+def paired_labels(rng, N, K, p_same=0.5):
+    h = N // 2
+    ids = rng.integers(0, K, size=N)
+    same = rng.random(h) < p_same
+    ids[h:][same] = ids[:h][same]
+    return ids.astype(np.float32).reshape(1, N)
+
+
+@pytest.mark.parametrize('D,N', [(160, 128), (512, 128), (160, 256), (160, 2), (23, 34)])
+@pytest.mark.parametrize('m', [-1.0, 3.0])
+def test_l2sn(D, N, m):
+    rng = np.random.default_rng(25)
+    data = mk(rng, D, N, scale=0.3)
+    ids = paired_labels(rng, N, 10575)
+    h = N // 2
+    wout, wm, widx, wd, wl = O.l2sn_cost(ids, data, D, N, m)
+    d_out, d_info, d_stats, d_cost = dev_empty((1, h), np.nan), dev_empty(4, np.nan), dev_empty(2 * h, np.nan), dev_double(1)
+    call('mcn_l2sn_cost', dev(ids), dev(data), d_out, D, N, m, d_info, d_stats, d_cost, None, None, 0, None)
+    stats = d_stats.numpy()
+    assert np.array_equal(stats[:h], wd), 'pair distances must be bit-identical (shared reduction order)'
+    assert np.array_equal(stats[h:], wl)
+    info = d_info.numpy()
+    assert info[0] == np.float32(wm) and int(info[1]) == widx, 'margin / chosen pair must agree exactly'
+    assert np.array_equal(d_out.numpy() != 0, wout != 0), '1[d<m] decisions must agree exactly'
+    close(d_out.numpy(), wout, rtol=1e-6, what='l2sn cost')
+    assert abs(d_cost.numpy()[0] - O.sum_all(wout)) <= 1e-6 * abs(O.sum_all(wout)) + 1e-9
+    for add in (0, 1):
+        t0 = mk(rng, D, N, scale=0.01)
+        wg = O.l2sn_grad(ids, data, D, N, 0.0025, m, target=t0.copy(), add=bool(add))
+        d_t = dev(t0)
+        call('mcn_l2sn_grad', dev(ids), dev(data), d_t, D, N, m, add, 0.0025, None, None, 0, None)
+        close(d_t.numpy(), wg, rtol=1e-6, atol=1e-9, what='l2sn grad')
+
+
+def test_l2sn_external_candidates():
+    """Multi-GPU: the margin is searched over the all-gathered pairs of every rank."""
+    rng = np.random.default_rng(26)
+    D, N, G = 160, 128, 4
+    h = N // 2
+    datas = [mk(rng, D, N, scale=0.3) for _ in range(G)]
+    idss = [paired_labels(rng, N, 10575) for _ in range(G)]
+    # the equivalent single-GPU minibatch: galleries of all ranks, then probes of all ranks
+    data_g = np.concatenate([d[:, :h] for d in datas] + [d[:, h:] for d in datas], axis=1)
+    ids_g = np.concatenate([i[:, :h] for i in idss] + [i[:, h:] for i in idss], axis=1)
+    wout, wm, widx, wd, wl = O.l2sn_cost(ids_g, np.ascontiguousarray(data_g), D, N * G, -1.0)
+    stats = []
+    for r in range(G):
+        d_stats = dev_empty(2 * h, np.nan)
+        call('mcn_l2sn_pair_stats', dev(idss[r]), dev(datas[r]), d_stats, D, N, None)
+        stats.append(d_stats.numpy())
+    ext_d = np.concatenate([s[:h] for s in stats])
+    ext_l = np.concatenate([s[h:] for s in stats])
+    assert np.array_equal(ext_d, wd) and np.array_equal(ext_l, wl)
+    wg = O.l2sn_grad(ids_g, np.ascontiguousarray(data_g), D, N * G, 0.0025, -1.0)
+    for r in range(G):
+        d_out, d_info = dev_empty((1, h), np.nan), dev_empty(4, np.nan)
+        call('mcn_l2sn_cost', dev(idss[r]), dev(datas[r]), d_out, D, N, -1.0, d_info, None, None, dev(ext_d), dev(ext_l), G * h, None)
+        info = d_info.numpy()
+        assert info[0] == np.float32(wm) and int(info[1]) == widx
+        close(d_out.numpy().reshape(-1), wout.reshape(-1)[r * h:(r + 1) * h], rtol=1e-6, what='l2sn cost rank %d' % r)
+        d_t = dev_empty((D, N), np.nan)
+        call('mcn_l2sn_grad', dev(idss[r]), dev(datas[r]), d_t, D, N, -1.0, 0, 0.0025, dev(ext_d), dev(ext_l), G * h, None)
+        got = d_t.numpy()
+        close(got[:, :h], wg[:, r * h:(r + 1) * h], rtol=1e-6, atol=1e-9, what='gallery grad rank %d' % r)
+        close(got[:, h:], wg[:, G * h + r * h:G * h + (r + 1) * h], rtol=1e-6, atol=1e-9, what='probe grad rank %d' % r)
+
+
+@pytest.mark.parametrize('D', [2, 27, 23])
+def test_l2reg(D):
+    rng = np.random.default_rng(27)
+    N = 128
+    gt, pred = mk(rng, D, N), mk(rng, D, N)
+    want = O.l2reg_cost(gt, pred, D, N)
+    d_o, d_cost = dev_empty((1, N), np.nan), dev_double(1)
+    call('mcn_l2reg_cost', dev(gt), dev(pred), d_o, D, N, d_cost, None)
+    close(d_o.numpy(), want, rtol=1e-6, what='l2reg cost')
+    assert abs(d_cost.numpy()[0] - O.sum_all(want)) <= 1e-6 * O.sum_all(want)
+    t0 = mk(rng, D, N)
+    wg = O.l2reg_grad(gt, pred, D, N, 0.01, target=t0.copy(), add=True)
+    d_t = dev(t0)
+    call('mcn_l2reg_grad', dev(gt), dev(pred), d_t, D, N, 1, 0.01, None)
+    close(d_t.numpy(), wg, rtol=1e-6, what='l2reg grad')
+
+
+# ----------------------------------------------------------------------------------- SGD update
+@pytest.mark.parametrize('n', [768, 28800 * 48, 1001])
+@pytest.mark.parametrize('use_grad,wc', [(1, 5e-4), (0, 5e-4), (1, 0.0)])
+def test_sgd_update(n, use_grad, wc):
+    rng = np.random.default_rng(28)
+    W, inc, grad = mk(rng, n, scale=0.04), mk(rng, n, scale=1e-3), mk(rng, n, scale=1e-4)
+    wW, wInc = W.copy(), inc.copy()
+    O.sgd_update(wW, wInc, grad, 0.9, wc, 5e-4, bool(use_grad))
+    d_W, d_inc = dev(W), dev(inc)
+    call('mcn_sgd_update', d_W, d_inc, dev(grad), n, 0.9, wc, 5e-4, use_grad, None)
+    close(d_inc.numpy(), wInc, rtol=1e-6, atol=1e-12, what='inc')
+    close(d_W.numpy(), wW, rtol=1e-6, what='W')
