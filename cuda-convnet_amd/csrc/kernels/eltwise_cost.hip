@@ -12,8 +12,8 @@
 // No multiply-add contraction in this file: the reference runs every NVMatrix op of the
 // cost layers as its own kernel (layer_kernels.cu:505-735), so products and sums are rounded
 // separately, and the L2-SN margin / 1[d<m] decisions are discontinuous in the last bit.
-// (HIP's __fmul_rn/__fadd_rn are plain operators and would be fused under the default
-// -ffp-contract=fast.)
+// HIP's __fmul_rn/__fadd_rn are plain operators defined in a header, so they would be fused
+// under the default -ffp-contract=fast: the Makefile builds this file with -ffp-contract=off.
 #pragma clang fp contract(off)
 
 #define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
