@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeepID2 Joint identification-verification training images/sec.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one minibatch (128 images per GPU, 55x55x3, 10575 identities; net =
+cuda-convnet_amd/cfg/deepid2_10575.cfg, the reference's deepid2/net-define-Joint-m0-10575.cfg)
+through fprop + bprop (softmax/logreg + L2-SN verification cost) + momentum/weight-decay update,
+fp32, on the `_ConvNet` extension (C++ layer graph -> C ABI -> hand-written HIP kernels).
+The synthetic data batch is resident in HBM before the timed region starts.  With N > 1 every
+rank is one replica (weak scaling, 128 images per GPU); weight gradients are all-reduced over
+RCCL inside the step.  torch is used only for the launcher plumbing (gloo barrier, broadcast of
+the RCCL unique id, max over ranks); no torch tensor touches the compute path.
+
+Prints ONE JSON line on rank 0 (see the README of the driver contract), including
+  roofline     -- the operation that takes the most device time in a step, timed live with HIP
+                  events on the net's own stream (the `_ConvNet` profiling pass right after the timed
+                  region, same process, same shapes) against its algorithmic FLOPs / bytes;
+  kernels      -- the same figures for every operation of the step;
+  cpu_baseline -- the CPU oracle (oracle/, a multithreaded C++ restatement of the reference
+                  semantics) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+
+def op_work(layers, label, N):
+    """Algorithmic work of one profiled operation: (flops, bytes, bound)."""
+    lname, op = label.rsplit('.', 1)
+    idx = 0
+    if '[' in op:
+        op, i = op[:-1].split('[')
+        idx = int(i)
+    l = next(x for x in layers if x['name'] == lname)
+    t = l['type']
+    if t in ('conv', 'local'):
+        M, F = l['modules'], l['filters']
+        C, fc, fp = l['channels'][idx], l['filterChannels'][idx], l['filterPixels'][idx]
+        img, out, nW = N * C * l['imgPixels'][idx], N * F * M, l['weights'][idx].size
+        if op in ('fprop', 'bpropActs', 'bpropWeights'):
+            return 2.0 * N * M * F * fc * fp, 4.0 * (img + out + nW), 'mfma'
+        if op == 'bpropBiases':
+            return out, 4.0 * out, 'hbm'
+    if t == 'fc':
+        I, O = l['numInputs'][idx], l['outputs']
+        if op in ('fprop', 'bpropActs', 'bpropWeights'):
+            return 2.0 * N * I * O, 4.0 * (N * I + N * O + I * O), 'mfma'
+        if op == 'bpropBiases':
+            return N * O, 4.0 * N * O, 'hbm'
+    if op == 'update':
+        n = sum(w.size for w in l['weights'])
+        per = 5 if t == 'conv' else 4  # useGrad: 3R + 2W, else 2R + 2W
+        return 3.0 * n, 4.0 * (per * n + 5 * l['biases'].size), 'hbm'
+    if t == 'pool':
+        inp, out = N * l['numInputs'][0], N * l['outputs']
+        if op == 'fprop':
+            return inp, 4.0 * (inp + out), 'hbm'
+        return inp, 4.0 * (2 * inp + 2 * out), 'hbm'  # max undo: imgs, maxActs, maxGrads -> target
+    if t == 'neuron':
+        n = N * l['outputs']
+        return n, (8.0 if op == 'fprop' else 12.0) * n, 'hbm'
+    if t == 'softmax':
+        return 4.0 * N * l['outputs'], 8.0 * N * l['outputs'], 'hbm'
+    if t in ('rnorm', 'cmrnorm'):
+        n = N * l['outputs']
+        return 2.0 * l['size'] * n, (12.0 if op == 'fprop' else 24.0) * n, 'hbm'
+    if t == 'cost.logreg':
+        K = layers[l['inputs'][1]]['outputs']
+        return N * K, 4.0 * N * K, 'hbm'
+    if t in ('cost.l2-sn', 'cost.l2-reg'):
+        D = layers[l['inputs'][1]]['outputs']
+        return 3.0 * N * D, (4.0 if op == 'fprop' else 12.0) * N * D, 'hbm'
+    n = N * l['outputs']
+    return n, 8.0 * n, 'hbm'
+
+
+def roofline_entry(layers, label, count, ms, N):
+    flops, nbytes, bound = op_work(layers, label, N)
+    t = ms / count * 1e-3
+    e = {'op': label, 'launches': count, 'avg_us': round(t * 1e6, 2), 'bound': bound}
+    if bound == 'mfma':
+        a = flops / t / 1e12
+        e.update(achieved=round(a, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(a / PEAK_FP32_MFMA_TFLOPS, 4),
+                 hbm_GBs=round(nbytes / t / 1e9, 1))
+    else:
+        a = nbytes / t / 1e9
+        e.update(achieved=round(a, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(a / PEAK_HBM_GBS, 4))
+    return e
+
+
+def cpu_baseline(preset, budget_s=15.0):
+    """The whole-net CPU oracle on a bounded sample of the same workload (images/sec on host cores)."""
+    import ccn_loader
+    ccn_loader.load()
+    from cuda_convnet_amd import CFG_DIR, layer
+    from cuda_convnet_amd.convnet import PRESETS
+    from cuda_convnet_amd.data import SyntheticDataProvider
+    from oracle.net import OracleNet
+    ldef, lpar, kind, img = PRESETS[preset]
+    dp = SyntheticDataProvider(kind, 128, img=img)
+    dims = {i: dp.get_data_dims(i) for i in range(len(dp.dims))}
+    L = layer.parse_layers(os.path.join(CFG_DIR, ldef), os.path.join(CFG_DIR, lpar), dims, dp.get_num_classes(), seed=3)
+    net = OracleNet(L, 128)
+    data = dp.get_next_batch()[2]
+    net.run_batch(data)  # warm-up (page in the library, first-touch the buffers)
+    t0 = time.time()
+    net.run_batch(data)
+    one = time.time() - t0
+    reps = int(max(1, min(32, budget_s / max(one, 1e-3))))
+    t0 = time.time()
+    for _ in range(reps):
+        net.run_batch(data)
+    dt = time.time() - t0
+    cores = int(os.environ.get('OMP_NUM_THREADS', 0)) or len(os.sched_getaffinity(0))
+    return {'value': round(reps * 128 / dt, 1), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d training minibatches of 128 (fprop+bprop+update), same net and synthetic data' % reps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='deepid2', help='preset name (cuda_convnet_amd.convnet.PRESETS)')
+    ap.add_argument('--minibatch', type=int, default=128)
+    ap.add_argument('--resident-minibatches', type=int, default=16)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--profile-steps', type=int, default=20)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
+        sys.exit('--gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
+
+    import numpy as np
+
+    import ccn_loader
+    ccn_loader.load()
+    from cuda_convnet_amd import CFG_DIR, layer
+    from cuda_convnet_amd.convnet import PRESETS, import_native
+    from cuda_convnet_amd.data import SyntheticDataProvider
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    lib = import_native()
+    ldef, lpar, kind, img = PRESETS[a.workload]
+    mb = a.minibatch
+    cases = mb * a.resident_minibatches
+    # every rank draws its own images (seed offset), identical initial weights (same parser seed)
+    dp = SyntheticDataProvider(kind, cases, img=img, minibatch=mb, seed=1 + 1000 * rank)
+    dims = {i: dp.get_data_dims(i) for i in range(len(dp.dims))}
+    layers = layer.parse_layers(os.path.join(CFG_DIR, ldef), os.path.join(CFG_DIR, lpar), dims, dp.get_num_classes(), seed=3)
+    data = dp.get_next_batch()[2]
+
+    lib.initModel(layers, mb, local)
+    if world > 1:
+        ids = [lib.commUniqueId() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        lib.initDataParallel(rank, world, ids[0])
+    lib.loadBatch(data)  # inputs resident in HBM from here on
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    lib.startSteps(a.warmup, 0, 0)
+    lib.finishBatch()
+    barrier()
+    t0 = time.perf_counter()
+    lib.startSteps(a.steps, 0, 0)
+    costs, ncases = lib.finishBatch()  # blocks until the stream has drained (device synchronised)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    assert ncases == a.steps * mb
+    for k, v in costs.items():
+        assert all(np.isfinite(v)), ('non-finite cost', k, v)
+
+    prof = {}
+    if not a.no_profile:
+        lib.startSteps(a.profile_steps, 0, 1)
+        lib.finishBatch()
+        prof = lib.getProfile()
+    lib.destroyModel()
+
+    if rank == 0:
+        out = {
+            'metric': 'DeepID2 train images/sec (node)', 'value': round(a.steps * mb * world / dt, 1), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s (%s) fprop+bprop+update, %dx%dx%d, %d ids, minibatch %d/GPU'
+                                   % (a.workload, ldef, img[0], img[1], img[2], dp.get_num_classes(), mb),
+                       'global_batch': mb * world, 'parallelism': 'dp%d' % world,
+                       'final_costs': {k: [x / ncases for x in v] for k, v in costs.items()}},
+        }
+        if prof:
+            ks = [roofline_entry(layers, lab, c, ms, mb) for lab, (c, ms) in prof.items() if c > 0]
+            ks.sort(key=lambda e: -e['avg_us'] * e['launches'])
+            step_us = sum(e['avg_us'] * e['launches'] for e in ks) / a.profile_steps
+            top = dict(ks[0])
+            out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'],
+                               'frac': top['frac'], 'traffic': None, 'kernel': top['op'], 'avg_us': top['avg_us']}
+            out['device_us_per_step'] = round(step_us, 1)
+            out['kernels'] = ks
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.workload)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,1050 @@
+// See net.h.  Reference citations are file:line into /root/reference/src unless noted.
+#include "net.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "mi_convnet.h"
+
+namespace mcn {
+
+void chk(int rc, const char* what) {
+    if (rc != MCN_OK) throw NetError(std::string(what) + ": " + mcn_last_error());
+}
+
+DBuf::~DBuf() {
+    if (p) mcn_free(p);
+}
+
+float* DBuf::ensure(size_t n) {
+    if (n > cap) {
+        if (p) chk(mcn_free(p), "free");
+        p = nullptr;
+        void* q = nullptr;
+        chk(mcn_alloc(&q, n * sizeof(float)), "alloc");
+        p = (float*)q;
+        cap = n;
+    }
+    return p;
+}
+
+static int neuronTypeId(const std::string& t) {
+    static const char* names[] = {"ident", "relu", "logistic", "brelu", "abs", "tanh", "softrelu", "square", "sqrt", "linear"};
+    for (int i = 0; i < 10; i++)
+        if (t == names[i]) return i;
+    throw NetError("unknown neuron type '" + t + "'");  // neuron.cu:32-75
+}
+
+bool NeuronSpec::needsInputs() const { return type == MCN_NEURON_ABS || type == MCN_NEURON_SQUARE; }
+bool NeuronSpec::fusableGrad() const { return !needsInputs() && type != MCN_NEURON_SOFTRELU; }
+
+// ============================================================================ Weights
+Weights::Weights(const HostMat& hW, const HostMat& hInc, float eps, float wc, float mom, bool useGrad, bool devFortran)
+    : _hW(hW), _hInc(hInc), _eps(eps), _wc(wc), _mom(mom), _useGrad(useGrad), _devFortran(devFortran) {
+    if (hW.rows != hInc.rows || hW.cols != hInc.cols) throw NetError("weights and weightsInc differ in shape");
+}
+
+Weights::Weights(Weights& src, float eps)
+    : _hW(src._hW), _hInc(src._hInc), _eps(eps), _wc(0), _mom(src._mom), _useGrad(src._useGrad),
+      _devFortran(src._devFortran), _src(src._src ? src._src : &src) {}
+
+void Weights::upload(const HostMat& h, float* dst, void* stream) {
+    const bool vec = h.rows == 1 || h.cols == 1;
+    if (vec || h.fortran == _devFortran) {
+        chk(mcn_h2d(dst, h.data, h.size() * 4, stream), "h2d weights");
+        chk(mcn_stream_sync(stream), "sync");
+        return;
+    }
+    std::vector<float> tmp(h.size());
+    for (long r = 0; r < h.rows; r++)
+        for (long c = 0; c < h.cols; c++)
+            tmp[memIndex(r, c)] = h.data[h.fortran ? c * h.rows + r : r * h.cols + c];
+    chk(mcn_h2d(dst, tmp.data(), tmp.size() * 4, stream), "h2d weights");
+    chk(mcn_stream_sync(stream), "sync");
+}
+
+void Weights::download(const HostMat& h, const float* src, void* stream) {
+    const bool vec = h.rows == 1 || h.cols == 1;
+    if (vec || h.fortran == _devFortran) {
+        chk(mcn_d2h(h.data, src, h.size() * 4, stream), "d2h weights");
+        chk(mcn_stream_sync(stream), "sync");
+        return;
+    }
+    std::vector<float> tmp(h.size());
+    chk(mcn_d2h(tmp.data(), src, tmp.size() * 4, stream), "d2h weights");
+    chk(mcn_stream_sync(stream), "sync");
+    for (long r = 0; r < h.rows; r++)
+        for (long c = 0; c < h.cols; c++)
+            h.data[h.fortran ? c * h.rows + r : r * h.cols + c] = tmp[memIndex(r, c)];
+}
+
+void Weights::copyToGPU(void* stream) {  // weights.cuh:134-147
+    if (_src) return;
+    _W.ensure(size());
+    _inc.ensure(size());
+    upload(_hW, _W.p, stream);
+    upload(_hInc, _inc.p, stream);
+}
+
+void Weights::copyToCPU(void* stream) {  // weights.cuh:124-130: fills the caller's arrays in place
+    if (_src) return;
+    download(_hW, _W.p, stream);
+    download(_hInc, _inc.p, stream);
+}
+
+void Weights::update(bool dp, void* stream) {
+    if (_src == nullptr && _eps > 0) {
+        chk(mcn_sgd_update(_W.p, _inc.p, _grad, size(), _mom, _wc, _eps, (_useGrad || dp) ? 1 : 0, stream), "sgd update");
+        _numUpdates = 0;
+    }
+}
+
+void Weights::hostImage(std::vector<float>& out, void* stream) {
+    std::vector<float> tmp(size());
+    chk(mcn_d2h(tmp.data(), W(), size() * 4, stream), "d2h");
+    chk(mcn_stream_sync(stream), "sync");
+    out.resize(size());
+    for (long r = 0; r < rows(); r++)
+        for (long c = 0; c < cols(); c++) out[(size_t)r * cols() + c] = tmp[memIndex(r, c)];
+}
+
+void Weights::setElement(long r, long c, float v, void* stream) {
+    chk(mcn_h2d(W() + memIndex(r, c), &v, 4, stream), "h2d element");
+    chk(mcn_stream_sync(stream), "sync");
+}
+
+// ============================================================================ Layer
+Layer::Layer(ConvNet* net, const Params& p) : _net(net) {  // layer.cu:44-57
+    _name = pstr(p, "name");
+    _type = pstr(p, "type");
+    _outputs = (int)pint(p, "outputs", 0);
+    _gradConsumer = pint(p, "gradConsumer") != 0;
+    _actsTarget = (int)pint(p, "actsTarget");
+    _actsGradTarget = (int)pint(p, "actsGradTarget");
+}
+
+float* Layer::getActs() {
+    if (!_acts) throw NetError("layer '" + _name + "' has no activities yet");
+    return _acts;
+}
+
+float* Layer::getActsGrad() {
+    if (_actsGradTarget >= 0) return _prev[_actsGradTarget]->getActsGrad();
+    return _ownActsGrad.p;
+}
+
+bool Layer::isGradConsumer() {  // layer.cu:202-210
+    if (!_foundGradConsumers) {
+        for (Layer* l : _prev) _gradConsumer |= l->isGradConsumer();
+        _foundGradConsumers = true;
+    }
+    return _gradConsumer;
+}
+
+void Layer::allocate(int maxCases) {
+    if (_actsTarget < 0) _ownActs.ensure(std::max<size_t>(actsElems(maxCases), 4));
+    if (_actsGradTarget < 0 && isGradConsumer() && _outputs > 0) _ownActsGrad.ensure((size_t)_outputs * maxCases);
+}
+
+void Layer::fpropFromPrev(PassType pt) {  // layer.cu:75-84
+    _rcvdF += 1;
+    if (_rcvdF == (int)_prev.size()) {
+        std::vector<float*> v;
+        for (Layer* l : _prev) v.push_back(l->getActs());
+        fprop(v, pt);
+    }
+}
+
+void Layer::fprop(const std::vector<float*>& inputs, PassType pt) {  // layer.cu:92-114
+    if (inputs.size() != _prev.size()) throw NetError("layer '" + _name + "': wrong number of inputs");
+    _inputs = inputs;
+    _acts = _actsTarget < 0 ? _ownActs.p : _inputs[_actsTarget];
+    _rcvdF = (int)_prev.size();
+    if (_actsTarget >= 0) {
+        ProfScope ps(_net, _name, "fprop", _actsTarget);
+        fpropActs(_actsTarget, 0, pt);
+    }
+    for (int i = 0; i < (int)_prev.size(); i++)
+        if (i != _actsTarget) {
+            ProfScope ps(_net, _name, "fprop", i);
+            fpropActs(i, (_actsTarget >= 0 || i > 0) ? 1.f : 0.f, pt);
+        }
+    for (Layer* l : _next) l->fpropFromPrev(pt);
+}
+
+void Layer::bprop(PassType pt) {  // layer.cu:116-121
+    if (_rcvdB == _numGradProducersNext) {
+        _rcvdB++;
+        bpropWith(getActsGrad(), pt);
+    }
+}
+
+void Layer::bpropWith(float* v, PassType pt) {  // layer.cu:123-158
+    bpropCommon(v, pt);
+    if (isGradProducer()) {
+        for (int i = 0; i < (int)_prev.size(); i++) {
+            if (_prev[i]->isGradConsumer() && _actsGradTarget != i) {
+                ProfScope ps(_net, _name, "bpropActs", i);
+                bpropActs(v, i, _prev[i]->rcvdB() > 0 ? 1.f : 0.f, pt);
+                _prev[i]->incRcvdB();
+            }
+        }
+        if (_actsGradTarget >= 0 && _prev[_actsGradTarget]->isGradConsumer()) {
+            ProfScope ps(_net, _name, "bpropActs", _actsGradTarget);
+            bpropActs(v, _actsGradTarget, _prev[_actsGradTarget]->rcvdB() > 0 ? 1.f : 0.f, pt);
+            _prev[_actsGradTarget]->incRcvdB();
+        }
+        for (Layer* l : _prev)
+            if (l->isGradConsumer()) l->bprop(pt);
+    }
+}
+
+// ============================================================================ NeuronLayer (layer.cu:240-251)
+NeuronLayer::NeuronLayer(ConvNet* net, const Params& p) : Layer(net, p) {
+    const Value& nv = pget(p, "neuron");
+    if (nv.kind != Value::DICT) throw NetError("layer '" + _name + "': 'neuron' must be a dict");
+    spec.type = neuronTypeId(pstr(*nv.dict, "type"));
+    if (phas(*nv.dict, "params")) {
+        const Value& pv = pget(*nv.dict, "params");
+        if (pv.kind == Value::DICT) {
+            if (phas(*pv.dict, "a")) spec.a = (float)pfloat(*pv.dict, "a");
+            if (phas(*pv.dict, "b")) spec.b = (float)pfloat(*pv.dict, "b");
+        }
+    }
+}
+
+void NeuronLayer::fpropActs(int, float, PassType) {
+    if (fwdFused) return;  // the producer's epilogue already applied the activation in place
+    if (spec.type == MCN_NEURON_IDENT && _acts == _inputs[0]) return;
+    chk(mcn_neuron_fwd(_inputs[0], _acts, (size_t)_outputs * _net->numCases(), spec.type, spec.a, spec.b, _net->stream()), "neuron fwd");
+}
+
+void NeuronLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
+    if (bwdFused) return;  // the max-pool undo above already wrote neuronGrad(undo) into the shared gradient
+    float* tgt = _prev[0]->getActsGrad();
+    chk(mcn_neuron_bwd(v, _acts, _inputs[0], tgt, (size_t)_outputs * _net->numCases(), spec.type, spec.a, spec.b,
+                       scaleTargets > 0 ? 1 : 0, _net->stream()), "neuron bwd");
+}
+
+// ============================================================================ WeightLayer (layer.cu:258-343)
+WeightLayer::WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortran) : Layer(net, p) {
+    std::vector<HostMat> hW = pmatv(p, "weights"), hInc = pmatv(p, "weightsInc");
+    HostMat hB = pmat(p, "biases"), hBInc = pmat(p, "biasesInc");
+    std::vector<double> momW = pfloatv(p, "momW"), epsW = pfloatv(p, "epsW"), wc = pfloatv(p, "wc");
+    std::vector<long> srcL = pintv(p, "weightSourceLayerIndices"), srcM = pintv(p, "weightSourceMatrixIndices");
+    if (hW.size() != hInc.size() || hW.size() != epsW.size() || hW.size() != momW.size() || hW.size() != wc.size() ||
+        hW.size() != srcL.size() || hW.size() != srcM.size())
+        throw NetError("layer '" + _name + "': weight parameter lists differ in length");
+    for (size_t i = 0; i < hW.size(); i++) {
+        if (srcL[i] == net->numLayers()) {  // current layer (layer.cu:280-281)
+            _weights.emplace_back(new Weights(*_weights.at(srcM[i]), (float)epsW[i]));
+        } else if (srcL[i] >= 0) {
+            WeightLayer* src = dynamic_cast<WeightLayer*>(&net->layer((int)srcL[i]));
+            if (!src) throw NetError("layer '" + _name + "': weight source is not a weight layer");
+            _weights.emplace_back(new Weights(src->weights((int)srcM[i]), (float)epsW[i]));
+        } else {
+            _weights.emplace_back(new Weights(hW[i], hInc[i], (float)epsW[i], (float)wc[i], (float)momW[i], useGrad, fortran));
+        }
+    }
+    _biases.reset(new Weights(hB, hBInc, (float)pfloat(p, "epsB"), 0.f, (float)pfloat(p, "momB"), true, false));
+}
+
+float WeightLayer::gradScale(float eps, PassType pt) const {
+    return pt == PASS_GC ? 1.f : eps / (float)(_net->numCases() * _net->worldSize());
+}
+
+void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
+    if (_biases->eps() > 0) {
+        ProfScope ps(_net, _name, "bpropBiases");
+        bpropBiases(v, pt);
+    }
+    for (int i = 0; i < (int)_weights.size(); i++) {
+        if (_weights[i]->eps() > 0) {
+            ProfScope ps(_net, _name, "bpropWeights", i);
+            bpropWeights(v, i, pt);
+            _weights[i]->incNumUpdates();
+        }
+    }
+    if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
+}
+
+void WeightLayer::updateWeights() {
+    ProfScope ps(_net, _name, "update");
+    for (auto& w : _weights) w->update(_net->dataParallel(), _net->stream());
+    _biases->update(_net->dataParallel(), _net->stream());
+}
+void WeightLayer::copyToCPU() {
+    for (auto& w : _weights) w->copyToCPU(_net->stream());
+    _biases->copyToCPU(_net->stream());
+}
+void WeightLayer::copyToGPU() {
+    for (auto& w : _weights) w->copyToGPU(_net->stream());
+    _biases->copyToGPU(_net->stream());
+}
+void WeightLayer::collectWeights(std::vector<Weights*>& out) {
+    for (auto& w : _weights) out.push_back(w.get());
+    out.push_back(_biases.get());
+}
+void WeightLayer::checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) {  // layer.cu:334-339
+    for (int i = 0; i < (int)_weights.size(); i++)
+        _net->checkGradient(_name + " weights[" + std::to_string(i) + "]", _wStep, *_weights[i], out, maxElems, central);
+    _net->checkGradient(_name + " biases", _bStep, *_biases, out, maxElems, central);
+}
+
+// ============================================================================ FCLayer (layer.cu:350-384)
+// Memory image of W_i is [outputs][inputs_i] (Fortran-order (inputs, outputs) host matrix,
+// layer.py:788); activities are (features, cases).  fwd: Y = W X; bwd-data: dX = W^T dY;
+// bwd-weights: inc = mom*inc + (eps/N) dY X^T.
+FCLayer::FCLayer(ConvNet* net, const Params& p) : WeightLayer(net, p, false, true) {
+    _wStep = 0.1f;  // layer.cu:351-352
+    _bStep = 0.01f;
+}
+
+size_t FCLayer::workspaceBytes(int maxCases) {
+    size_t b = mcn_add_sum_workspace_bytes(_outputs, maxCases, 1);
+    for (Layer* l : _prev) {
+        const int I = l->outputs();
+        b = std::max(b, mcn_gemm_workspace_bytes(_outputs, maxCases, I, 0, 0));
+        b = std::max(b, mcn_gemm_workspace_bytes(I, maxCases, _outputs, 1, 0));
+        b = std::max(b, mcn_gemm_workspace_bytes(_outputs, I, maxCases, 0, 1));
+    }
+    return b;
+}
+
+void FCLayer::fpropActs(int i, float scaleTargets, PassType) {
+    const int n = _net->numCases(), I = _prev[i]->outputs();
+    if (scaleTargets == 0) {
+        const bool fuse = fusedNeuron && _prev.size() == 1;
+        chk(mcn_gemm_bias_neuron(_weights[i]->W(), _inputs[i], _biases->W(), _acts, _outputs, n, I, 0.f,
+                                 fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fuse ? fusedNeuron->spec.a : 0.f,
+                                 fuse ? fusedNeuron->spec.b : 0.f, _net->workspace(), _net->workspaceBytes(), _net->stream()),
+            "fc fprop");
+    } else {
+        chk(mcn_gemm(_weights[i]->W(), _inputs[i], _acts, _outputs, n, I, 0, 0, 1.f, scaleTargets, _net->workspace(),
+                     _net->workspaceBytes(), _net->stream()), "fc fprop");
+    }
+}
+
+void FCLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {
+    const int n = _net->numCases(), I = _prev[i]->outputs();
+    chk(mcn_gemm(_weights[i]->W(), v, _prev[i]->getActsGrad(), I, n, _outputs, 1, 0, 1.f, scaleTargets, _net->workspace(),
+                 _net->workspaceBytes(), _net->stream()), "fc bprop acts");
+}
+
+void FCLayer::bpropBiases(float* v, PassType pt) {
+    chk(mcn_add_sum(_biases->gradBuf(), v, _outputs, _net->numCases(), 1, 0.f, gradScale(_biases->eps(), pt), _net->workspace(),
+                    _net->workspaceBytes(), _net->stream()), "fc bprop biases");
+}
+
+void FCLayer::bpropWeights(float* v, int i, PassType pt) {
+    const int n = _net->numCases(), I = _prev[i]->outputs();
+    Weights& w = *_weights[i];
+    const bool dp = _net->dataParallel();
+    // single GPU: momentum folded into the GEMM epilogue (layer.cu:378-381); data-parallel: raw
+    // scaled gradient, momentum applied after the all-reduce (algebraically identical)
+    const float scaleTgt = dp ? (w.numUpdates() > 0 ? 1.f : 0.f) : ((w.numUpdates() == 0 && pt != PASS_GC) ? w.mom() : 0.f);
+    chk(mcn_gemm(v, _prev[i]->getActs(), w.getGrad(dp), _outputs, I, n, 0, 1, gradScale(w.eps(), pt), scaleTgt, _net->workspace(),
+                 _net->workspaceBytes(), _net->stream()), "fc bprop weights");
+}
+
+// ============================================================================ LocalLayer / ConvLayer / LocalUnsharedLayer
+LocalLayer::LocalLayer(ConvNet* net, const Params& p, bool useGrad, bool conv) : WeightLayer(net, p, useGrad, false), _conv(conv) {
+    _padding = pintv(p, "padding");  // layer.cu:393-407
+    _stride = pintv(p, "stride");
+    _filterSize = pintv(p, "filterSize");
+    _channels = pintv(p, "channels");
+    _groups = pintv(p, "groups");
+    _filterChannels = pintv(p, "filterChannels");
+    std::vector<long> imgSize = pintv(p, "imgSize");
+    _imgSizeX = phas(p, "imgSizeX") ? pintv(p, "imgSizeX") : imgSize;  // rectangular extension
+    _imgSizeY = phas(p, "imgSizeY") ? pintv(p, "imgSizeY") : imgSize;
+    _filters = (int)pint(p, "filters");
+    _modulesX = (int)pint(p, "modulesX");
+    _modulesY = (int)pint(p, "modulesY", _modulesX);
+    _modules = (int)pint(p, "modules");
+    if (_modules != _modulesX * _modulesY) throw NetError("layer '" + _name + "': modules != modulesY*modulesX");
+    if (phas(p, "randSparse"))
+        for (long r : pintv(p, "randSparse"))
+            if (r) throw NetError("layer '" + _name + "': random-sparse connectivity is outside the scope of this build");
+    if (conv) {
+        _partialSum = (int)pint(p, "partialSum");  // layer.cu:439-440
+        _sharedBiases = (int)pint(p, "sharedBiases");
+    }
+}
+
+size_t LocalLayer::workspaceBytes(int maxCases) {
+    size_t b = (_conv && _sharedBiases) ? mcn_add_sum_workspace_bytes(_filters, _modules * maxCases, 1)
+                                        : mcn_add_sum_workspace_bytes(_filters * _modules, maxCases, 1);
+    if (_conv)
+        for (size_t i = 0; i < _prev.size(); i++)
+            b = std::max(b, mcn_conv_weight_acts_reduced_workspace_bytes((int)_channels[i], _filters, (int)_filterSize[i], _modulesY,
+                                                                        _modulesX, (int)_groups[i]));
+    return b;
+}
+
+void LocalLayer::fpropActs(int i, float scaleTargets, PassType) {  // layer.cu:443-462, :530-543
+    const int n = _net->numCases();
+    if (scaleTargets == 0) {
+        const bool fuse = fusedNeuron && _prev.size() == 1;
+        chk(mcn_filter_acts_bias_neuron(_inputs[i], _weights[i]->W(), _biases->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i],
+                                        (int)_channels[i], _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
+                                        (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, (_conv && _sharedBiases) ? 0 : 1,
+                                        fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fuse ? fusedNeuron->spec.a : 0.f,
+                                        fuse ? fusedNeuron->spec.b : 0.f, _net->stream()), "filterActs");
+    } else {
+        auto fn = _conv ? mcn_conv_filter_acts : mcn_local_filter_acts;
+        chk(fn(_inputs[i], _weights[i]->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i], _filters,
+               (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], scaleTargets, 1.f,
+               _net->stream()), "filterActs");
+    }
+}
+
+void LocalLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {  // layer.cu:498-513, :566-575
+    auto fn = _conv ? mcn_conv_img_acts : mcn_local_img_acts;
+    chk(fn(v, _weights[i]->W(), _prev[i]->getActsGrad(), _net->numCases(), (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i],
+           _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], scaleTargets, 1.f,
+           _net->stream()), "imgActs");
+}
+
+void LocalLayer::bpropBiases(float* v, PassType pt) {  // layer.cu:464-474, :545-549
+    const int n = _net->numCases();
+    const float sc = gradScale(_biases->eps(), pt);
+    if (_conv && _sharedBiases)
+        chk(mcn_add_sum(_biases->gradBuf(), v, _filters, _modules * n, 1, 0.f, sc, _net->workspace(), _net->workspaceBytes(), _net->stream()),
+            "conv bprop biases");
+    else
+        chk(mcn_add_sum(_biases->gradBuf(), v, _filters * _modules, n, 1, 0.f, sc, _net->workspace(), _net->workspaceBytes(), _net->stream()),
+            "local bprop biases");
+}
+
+void LocalLayer::bpropWeights(float* v, int i, PassType pt) {
+    const int n = _net->numCases();
+    Weights& w = *_weights[i];
+    const bool dp = _net->dataParallel();
+    if (_conv) {
+        // layer.cu:476-496: weightActs into a (modules/partialSum) x weights temporary, then addSum over
+        // its rows.  Here: one call with a private module split + fixed-order reduction; the value is
+        // the sum over ALL modules either way, so `partialSum` only affects rounding order.
+        chk(mcn_conv_weight_acts_reduced(_prev[i]->getActs(), v, w.getGrad(dp), _net->workspace(), _net->workspaceBytes(), n, n,
+                                         (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i], _filters, (int)_filterSize[i],
+                                         _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i],
+                                         w.numUpdates() > 0 ? 1.f : 0.f, gradScale(w.eps(), pt), _net->stream()), "convWeightActs");
+    } else {
+        // layer.cu:551-564: straight into inc with momentum (single GPU) / raw gradient (data-parallel)
+        const float scaleTgt = dp ? (w.numUpdates() > 0 ? 1.f : 0.f) : ((pt != PASS_GC && w.numUpdates() == 0) ? w.mom() : 0.f);
+        chk(mcn_local_weight_acts(_prev[i]->getActs(), v, w.getGrad(dp), n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i],
+                                  _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i],
+                                  (int)_groups[i], scaleTgt, gradScale(w.eps(), pt), _net->stream()), "localWeightActs");
+    }
+}
+
+// ============================================================================ SoftmaxLayer (layer.cu:582-607)
+size_t SoftmaxLayer::workspaceBytes(int maxCases) { return mcn_softmax_workspace_bytes(_outputs, maxCases); }
+
+void SoftmaxLayer::fpropActs(int, float, PassType) {
+    chk(mcn_softmax(_inputs[0], _acts, _outputs, _net->numCases(), _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax");
+}
+
+void SoftmaxLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
+    const bool doLogregGrad = _next.size() == 1 && _next[0]->type() == "cost.logreg";
+    if (doLogregGrad) {
+        float* labels = _next[0]->prev()[0]->getActs();
+        const float coeff = static_cast<CostLayer*>(_next[0])->coeff();
+        chk(mcn_logreg_softmax_grad(labels, _acts, _prev[0]->getActsGrad(), _outputs, _net->numCases(), scaleTargets == 1 ? 1 : 0, coeff,
+                                    _net->stream()), "logreg-softmax grad");
+    } else {
+        chk(mcn_softmax_grad(_acts, v, _prev[0]->getActsGrad(), _outputs, _net->numCases(), scaleTargets == 1 ? 1 : 0, _net->stream()),
+            "softmax grad");
+    }
+}
+
+// ============================================================================ Eltwise layers (layer.cu:614-653)
+EltwiseSumLayer::EltwiseSumLayer(ConvNet* net, const Params& p) : Layer(net, p) { _coeffs = pfloatv(p, "coeffs"); }
+
+void EltwiseSumLayer::fpropActs(int i, float scaleTargets, PassType) {
+    const size_t n = (size_t)_outputs * _net->numCases();
+    if (scaleTargets == 0) chk(mcn_scale(_inputs[i], _acts, n, (float)_coeffs[i], _net->stream()), "eltsum");
+    else chk(mcn_axpby(_acts, _inputs[i], n, 1.f, (float)_coeffs[i], _net->stream()), "eltsum");
+}
+
+void EltwiseSumLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {
+    const size_t n = (size_t)_outputs * _net->numCases();
+    float* tgt = _prev[i]->getActsGrad();
+    if (scaleTargets == 0) chk(mcn_scale(v, tgt, n, (float)_coeffs[i], _net->stream()), "eltsum grad");
+    else chk(mcn_axpby(tgt, v, n, scaleTargets, (float)_coeffs[i], _net->stream()), "eltsum grad");
+}
+
+void EltwiseMaxLayer::fpropActs(int i, float, PassType) {
+    const size_t n = (size_t)_outputs * _net->numCases();
+    if (i == 1) chk(mcn_eltwise_max(_inputs[1], _inputs[0], _acts, n, _net->stream()), "eltmax");
+    else if (i > 1) chk(mcn_eltwise_max(_acts, _inputs[i], _acts, n, _net->stream()), "eltmax");
+}
+
+void EltwiseMaxLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {
+    chk(mcn_eltwise_max_grad(v, _inputs[i], _acts, _prev[i]->getActsGrad(), (size_t)_outputs * _net->numCases(), scaleTargets != 0 ? 1 : 0,
+                             _net->stream()), "eltmax grad");
+}
+
+// ============================================================================ DataLayer (layer.cu:660-679)
+DataLayer::DataLayer(ConvNet* net, const Params& p) : Layer(net, p) { dataIdx = (int)pint(p, "dataIdx"); }
+
+void DataLayer::fpropData(float* slice, PassType pt) {
+    _acts = slice;
+    for (Layer* l : _next) l->fpropFromPrev(pt);
+}
+
+// ============================================================================ PoolLayer (layer.cu:685-736)
+PoolLayer::PoolLayer(ConvNet* net, const Params& p) : Layer(net, p) {
+    _channels = (int)pint(p, "channels");
+    _sizeX = (int)pint(p, "sizeX");
+    _start = (int)pint(p, "start");
+    _stride = (int)pint(p, "stride");
+    _outputsX = (int)pint(p, "outputsX");
+    _outputsY = (int)pint(p, "outputsY", _outputsX);
+    const int imgSize = (int)pint(p, "imgSize");
+    _imgSizeX = (int)pint(p, "imgSizeX", imgSize);
+    _imgSizeY = (int)pint(p, "imgSizeY", imgSize);
+    const std::string& pool = pstr(p, "pool");
+    if (pool != "max" && pool != "avg") throw NetError("Unknown pooling layer type " + pool);  // layer.cu:706
+    _max = pool == "max";
+}
+
+void PoolLayer::fpropActs(int, float, PassType) {
+    chk(mcn_local_pool(_inputs[0], _acts, _net->numCases(), _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride, _outputsY, _outputsX,
+                       _max ? 0 : 1, _net->stream()), "pool");
+}
+
+void PoolLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
+    float* tgt = _prev[0]->getActsGrad();
+    const int n = _net->numCases();
+    if (!_max) {
+        chk(mcn_local_avg_undo(v, tgt, n, _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride, _outputsY, _outputsX, scaleTargets, 1.f,
+                               _net->stream()), "avg undo");
+    } else if (fusedNeuronGrad && scaleTargets == 0) {
+        chk(mcn_local_max_undo_neuron(_prev[0]->getActs(), v, _acts, tgt, n, _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride,
+                                      _outputsY, _outputsX, fusedNeuronGrad->spec.type, fusedNeuronGrad->spec.a, fusedNeuronGrad->spec.b,
+                                      _net->stream()), "max undo + neuron grad");
+    } else {
+        if (fusedNeuronGrad) throw NetError("layer '" + _name + "': fused neuron gradient with accumulation");
+        chk(mcn_local_max_undo(_prev[0]->getActs(), v, _acts, tgt, n, _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride, _outputsY,
+                               _outputsX, scaleTargets, 1.f, _net->stream()), "max undo");
+    }
+}
+
+// ============================================================================ ResponseNormLayer (layer.cu:847-885)
+ResponseNormLayer::ResponseNormLayer(ConvNet* net, const Params& p, bool cross) : Layer(net, p), _cross(cross) {
+    _channels = (int)pint(p, "channels");
+    _size = (int)pint(p, "size");
+    _scale = (float)pfloat(p, "scale");
+    _pow = (float)pfloat(p, "pow");
+    _blocked = (int)pint(p, "blocked", 0);
+    const int imgSize = (int)pint(p, "imgSize", 0);
+    _imgSizeX = (int)pint(p, "imgSizeX", imgSize);
+    _imgSizeY = (int)pint(p, "imgSizeY", imgSize);
+    if ((long)_channels * _imgSizeX * _imgSizeY != _outputs) throw NetError("layer '" + _name + "': geometry does not match outputs");
+}
+
+void ResponseNormLayer::allocate(int maxCases) {
+    Layer::allocate(maxCases);
+    _denoms.ensure((size_t)_outputs * maxCases);
+}
+
+void ResponseNormLayer::fpropActs(int, float, PassType) {
+    const int n = _net->numCases();
+    if (_cross)
+        chk(mcn_response_norm_cross_map(_inputs[0], _denoms.p, _acts, n, _channels, _imgSizeY * _imgSizeX, _size, _scale, _pow, _blocked,
+                                        _net->stream()), "cmrnorm");
+    else
+        chk(mcn_response_norm(_inputs[0], _denoms.p, _acts, n, _channels, _imgSizeY, _imgSizeX, _size, _scale, _pow, _net->stream()), "rnorm");
+}
+
+void ResponseNormLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // destroys own acts like the reference
+    const int n = _net->numCases();
+    if (_cross)
+        chk(mcn_response_norm_cross_map_undo(v, _denoms.p, _prev[0]->getActs(), _acts, _prev[0]->getActsGrad(), n, _channels,
+                                             _imgSizeY * _imgSizeX, _size, _scale, _pow, _blocked, scaleTargets, 1.f, _net->stream()),
+            "cmrnorm undo");
+    else
+        chk(mcn_response_norm_undo(v, _denoms.p, _prev[0]->getActs(), _acts, _prev[0]->getActsGrad(), n, _channels, _imgSizeY, _imgSizeX,
+                                   _size, _scale, _pow, scaleTargets, 1.f, _net->stream()), "rnorm undo");
+}
+
+// ============================================================================ Cost layers (layer.cu:920-1116)
+CostLayer::CostLayer(ConvNet* net, const Params& p) : Layer(net, p) { _coeff = (float)pfloat(p, "coeff"); }
+
+void CostLayer::bprop(PassType pt) {
+    if (_coeff != 0) Layer::bprop(pt);
+}
+
+void CostLayer::allocate(int maxCases) {
+    _ownActs.ensure(std::max<size_t>(actsElems(maxCases), 4));
+    _aux.ensure(std::max<size_t>(maxCases, 4));
+}
+
+size_t LogregCostLayer::workspaceBytes(int maxCases) { return mcn_logreg_cost_workspace_bytes(_prev[1]->outputs(), maxCases); }
+
+void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
+    if (i != 0) return;
+    chk(mcn_logreg_cost(_inputs[0], _inputs[1], _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
+                        _net->workspaceBytes(), _net->stream()), "logreg cost");
+}
+
+void LogregCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:983-994
+    if (i != 1) throw NetError("logreg cost: gradient requested for the labels");
+    const bool doWork = _prev[1]->next().size() > 1 || _prev[1]->type() != "softmax";
+    if (doWork)
+        chk(mcn_logreg_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(),
+                            scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "logreg grad");
+}
+
+void SumOfSquaresCostLayer::fpropActs(int, float, PassType) {  // layer.cu:1004-1008
+    const size_t n = (size_t)_prev[0]->outputs() * _net->numCases();
+    chk(mcn_neuron_fwd(_inputs[0], _acts, n, MCN_NEURON_SQUARE, 0.f, 0.f, _net->stream()), "sum2 cost");
+    chk(mcn_sum_all(_acts, n, dCost, 1, _net->stream()), "sum2 cost");
+}
+
+void SumOfSquaresCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1010-1012
+    const size_t n = (size_t)_prev[0]->outputs() * _net->numCases();
+    float* tgt = _prev[i]->getActsGrad();
+    if (scaleTargets == 0) chk(mcn_scale(_inputs[0], tgt, n, -2 * _coeff, _net->stream()), "sum2 grad");
+    else chk(mcn_axpby(tgt, _inputs[0], n, scaleTargets, -2 * _coeff, _net->stream()), "sum2 grad");
+}
+
+L2SNCostLayer::L2SNCostLayer(ConvNet* net, const Params& p) : CostLayer(net, p) { _m = (float)pfloat(p, "m"); }  // layer.cu:1055-1058
+
+void L2SNCostLayer::allocate(int maxCases) {
+    CostLayer::allocate(maxCases);
+    _pairStats.ensure(std::max(maxCases, 4));
+    _gathered.ensure((size_t)std::max(maxCases, 4) * std::max(1, _net->worldSize()));
+}
+
+void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
+    if (i != 0) return;
+    const int n = _net->numCases(), D = _prev[1]->outputs(), h = n / 2;
+    _extCount = 0;
+    if (_net->dataParallel() && _m < 0) {
+        // the data-dependent margin must be the one a single GPU would pick on the global minibatch
+        // (SURVEY 8e): gather every rank's pair distances and labels, search over all of them
+        const int G = _net->worldSize();
+        _gathered.ensure((size_t)2 * h * G);
+        chk(mcn_l2sn_pair_stats(_inputs[0], _inputs[1], _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
+        _net->allGather(_pairStats.p, _gathered.p, h);
+        _net->allGather(_pairStats.p + h, _gathered.p + (size_t)h * G, h);
+        _extCount = h * G;
+    }
+    chk(mcn_l2sn_cost(_inputs[0], _inputs[1], _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
+                      _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+}
+
+void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
+    if (i != 1) return;
+    const int n = _net->numCases(), D = _prev[1]->outputs();
+    chk(mcn_l2sn_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), D, n, _m, scaleTargets == 1 ? 1 : 0, _coeff,
+                      _extCount ? _gathered.p : nullptr, _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()),
+        "l2sn grad");
+}
+
+void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
+    if (i != 0) return;
+    chk(mcn_l2reg_cost(_inputs[0], _inputs[1], _acts, _prev[1]->outputs(), _net->numCases(), dCost, _net->stream()), "l2reg cost");
+}
+
+void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1107-1116
+    if (i != 1) throw NetError("l2-reg cost: gradient requested for the targets");
+    chk(mcn_l2reg_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(),
+                       scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2reg grad");
+}
+
+// ============================================================================ DataProvider (data.cu)
+void DataProvider::setData(const CPUData& d) {
+    _host = d;
+    _numCases = d.numCases();
+    if (_numCases <= 0) throw NetError("data batch has no cases");
+    size_t bytes = 0;
+    _dims.clear();
+    for (const HostMat& m : d.mats) {
+        if (m.cols != _numCases) throw NetError("data matrices differ in the number of cases");
+        bytes += m.size() * 4;
+        _dims.push_back(m.rows);
+    }
+    while (_dev.size() < d.mats.size()) {
+        _dev.emplace_back(new DBuf());
+        _mini.emplace_back(new DBuf());
+    }
+    // The reference keeps a batch on the device below 200 MB (util.cuh:53) and otherwise uploads a
+    // host-side column slice per minibatch.  With 288 GB of HBM the whole batch is resident by default.
+    const char* env = getenv("MCN_MAX_DATA_ON_GPU_MB");
+    const size_t limitMB = env ? (size_t)atol(env) : 16384;
+    _onDevice = bytes / (1024 * 1024) < limitMB;
+    if (_onDevice) {
+        for (size_t i = 0; i < d.mats.size(); i++) {
+            _dev[i]->ensure(d.mats[i].size());
+            chk(mcn_h2d(_dev[i]->p, d.mats[i].data, d.mats[i].size() * 4, _net->stream()), "h2d data batch");
+        }
+        chk(mcn_stream_sync(_net->stream()), "sync");
+    }
+}
+
+void DataProvider::getSlice(long start, long end, std::vector<float*>& out) {
+    end = std::min(end, _numCases);
+    const long n = end - start;
+    if (n <= 0) throw NetError("empty data slice");
+    out.clear();
+    for (size_t i = 0; i < _dims.size(); i++) {
+        if (_onDevice && n == _numCases) {
+            out.push_back(_dev[i]->p);
+            continue;
+        }
+        _mini[i]->ensure((size_t)_dims[i] * _minibatchSize);
+        if (_onDevice) {
+            chk(mcn_copy2d(_mini[i]->p, n * 4, _dev[i]->p + start, _numCases * 4, n * 4, _dims[i], 2, _net->stream()), "slice data");
+        } else {
+            if (_host.mats.size() != _dims.size()) throw NetError("host data batch is gone");
+            chk(mcn_copy2d(_mini[i]->p, n * 4, _host.mats[i].data + start, _numCases * 4, n * 4, _dims[i], 0, _net->stream()), "upload slice");
+            chk(mcn_stream_sync(_net->stream()), "sync");
+        }
+        out.push_back(_mini[i]->p);
+    }
+}
+
+double Cost::value() const {
+    double v = 0;
+    for (auto& kv : values) v += coeffs.at(kv.first) * kv.second.at(0);
+    return v;
+}
+
+// ============================================================================ ConvNet (convnet.cu)
+ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int deviceID) : _minibatchSize(minibatchSize), _deviceID(deviceID) {
+    if (minibatchSize <= 0) throw NetError("minibatch size must be positive");
+    _fusion = getenv("MCN_NO_FUSION") == nullptr;  // debugging aid: run every layer as its own kernel(s)
+    for (const Params& p : layers) {  // convnet.cu:86-134
+        const std::string& t = pstr(p, "type");
+        Layer* l;
+        if (t == "fc") l = new FCLayer(this, p);
+        else if (t == "conv") l = new LocalLayer(this, p, true, true);
+        else if (t == "local") l = new LocalLayer(this, p, false, false);
+        else if (t == "pool") l = new PoolLayer(this, p);
+        else if (t == "rnorm") l = new ResponseNormLayer(this, p, false);
+        else if (t == "cmrnorm") l = new ResponseNormLayer(this, p, true);
+        else if (t == "softmax") l = new SoftmaxLayer(this, p);
+        else if (t == "eltsum") l = new EltwiseSumLayer(this, p);
+        else if (t == "eltmax") l = new EltwiseMaxLayer(this, p);
+        else if (t == "neuron") l = new NeuronLayer(this, p);
+        else if (t == "data") { auto* d = new DataLayer(this, p); _dataLayers.push_back(d); l = d; }
+        else if (t == "cost.logreg") { auto* c = new LogregCostLayer(this, p); _costs.push_back(c); l = c; }
+        else if (t == "cost.sum2") { auto* c = new SumOfSquaresCostLayer(this, p); _costs.push_back(c); l = c; }
+        else if (t == "cost.l2-sn") { auto* c = new L2SNCostLayer(this, p); _costs.push_back(c); l = c; }
+        else if (t == "cost.l2-reg") { auto* c = new L2regCostLayer(this, p); _costs.push_back(c); l = c; }
+        else throw NetError("Unknown layer type " + t);
+        _layers.emplace_back(l);
+        if (phas(p, "inputs"))
+            for (long i : pintv(p, "inputs")) {
+                if (i < 0 || i >= (long)_layers.size() - 1) throw NetError("layer '" + l->name() + "': bad input index");
+                l->addPrev(_layers[i].get());
+            }
+    }
+    for (auto& l : _layers)
+        for (Layer* p : l->prev()) p->addNext(l.get());
+    _dp.reset(new DataProvider(this, minibatchSize));
+}
+
+ConvNet::~ConvNet() {
+    stop();
+    for (void* e : _eventPool) mcn_event_destroy(e);
+}
+
+// Fused epilogues, decided once from the graph (no counterpart in the reference, which launches
+// bias add, neuron and pool-undo / neuron-gradient as separate kernels: layer.cu:249, :453-461, :734).
+void ConvNet::buildFusions() {
+    if (!_fusion) return;
+    for (auto& up : _layers) {
+        // forward: conv/local/fc with ONE input whose only consumer is a neuron layer sharing its activity matrix
+        if (auto* w = dynamic_cast<WeightLayer*>(up.get())) {
+            if (w->prev().size() == 1 && w->next().size() == 1) {
+                auto* r = dynamic_cast<NeuronLayer*>(w->next()[0]);
+                if (r && r->actsTarget() == 0 && r->prev().size() == 1) {
+                    w->fusedNeuron = r;
+                    r->fwdFused = true;
+                }
+            }
+        }
+        // backward: max pool directly above a neuron layer that (a) gets gradient from nobody else,
+        // (b) shares its gradient matrix with its producer and (c) has a gradient that needs only its output
+        if (auto* pl = dynamic_cast<PoolLayer*>(up.get())) {
+            auto* r = dynamic_cast<NeuronLayer*>(pl->prev()[0]);
+            if (pl->isMax() && r && r->actsGradTarget() == 0 && r->numGradProducersNext() == 1 && r->next().size() == 1 &&
+                r->spec.fusableGrad() && r->isGradConsumer()) {
+                pl->fusedNeuronGrad = r;
+                r->bwdFused = true;
+            }
+        }
+    }
+}
+
+void ConvNet::start() { _thread = std::thread([this] { run(); }); }
+
+void ConvNet::stop() {
+    if (_thread.joinable()) {
+        _work.enqueue([](ConvNet& n) { n._stop = true; });
+        _thread.join();
+    }
+}
+
+void ConvNet::run() {  // convnet.cu:147-156
+    try {
+        initDevice();
+        WorkResult r;
+        r.type = WorkResult::INIT_DONE;
+        _results.enqueue(std::move(r));
+    } catch (std::exception& e) {
+        WorkResult r;
+        r.type = WorkResult::ERROR;
+        r.error = e.what();
+        _results.enqueue(std::move(r));
+        return;
+    }
+    while (!_stop) {
+        Work w = _work.dequeue();
+        try {
+            w(*this);
+        } catch (std::exception& e) {
+            WorkResult r;
+            r.type = WorkResult::ERROR;
+            r.error = e.what();
+            _results.enqueue(std::move(r));
+        }
+    }
+}
+
+void ConvNet::initDevice() {  // convnet.cu:139-145
+    chk(mcn_set_device(_deviceID < 0 ? 0 : _deviceID), "set device");
+    chk(mcn_stream_create(&_stream), "stream");
+    for (auto& l : _layers) l->copyToGPU();
+    buildFusions();
+    allocate(_minibatchSize);
+}
+
+void ConvNet::allocate(int maxCases) {
+    for (auto& l : _layers) l->allocate(maxCases);
+    size_t ws = 256;
+    for (auto& l : _layers) ws = std::max(ws, l->workspaceBytes(maxCases));
+    _ws.ensure((ws + 3) / 4);
+    // gradient arena in reverse layer order == the order in which backward completes them, so that
+    // data-parallel buckets are contiguous ranges
+    const bool dp = dataParallel();
+    size_t total = 0;
+    _segments.clear();
+    std::vector<std::pair<Weights*, size_t>> place;
+    for (int i = (int)_layers.size() - 1; i >= 0; i--) {
+        auto* wl = dynamic_cast<WeightLayer*>(_layers[i].get());
+        if (!wl) continue;
+        std::vector<Weights*> ws_;
+        wl->collectWeights(ws_);
+        const size_t begin = total;
+        for (Weights* w : ws_) {
+            if (!w->owner() || !(w->useGrad() || dp)) continue;
+            place.emplace_back(w, total);
+            total += (w->size() + 3) & ~(size_t)3;
+        }
+        if (total > begin) _segments.push_back({wl, begin, total, false});
+    }
+    _gradArena.ensure(std::max<size_t>(total, 4));
+    chk(mcn_memset(_gradArena.p, 0, _gradArena.cap * 4, _stream), "memset grads");
+    for (auto& pw : place) pw.first->setGradBuf(_gradArena.p + pw.second);
+    int nc = 0;
+    for (CostLayer* c : _costs) nc += c->numCostValues();
+    _costBuf.ensure(std::max(2 * nc, 4));
+    _costHost.assign(nc, 0.0);
+    nc = 0;
+    for (CostLayer* c : _costs) {
+        c->dCost = reinterpret_cast<double*>(_costBuf.p) + nc;
+        nc += c->numCostValues();
+    }
+    zeroCosts();
+    _allocatedCases = maxCases;
+    chk(mcn_stream_sync(_stream), "sync");
+}
+
+void ConvNet::initComm(int rank, int world, const char* id128) {
+    if (world < 1 || rank < 0 || rank >= world) throw NetError("bad data-parallel rank / world size");
+    _rank = rank;
+    _world = world;
+    if (world > 1) {
+        chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
+        chk(mcn_stream_create(&_commStream), "comm stream");
+        chk(mcn_event_create(&_evGrad), "event");
+        chk(mcn_event_create(&_evComm), "event");
+        const char* env = getenv("MCN_BUCKET_MB");
+        _bucketFloats = (size_t)((env ? atof(env) : 4.0) * 1024 * 1024 / 4);
+        allocate(_minibatchSize);  // every weight matrix now needs a gradient buffer in the arena
+    }
+}
+
+void ConvNet::sync() { chk(mcn_stream_sync(_stream), "sync"); }
+
+void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
+    for (auto& l : _layers) l->reset();
+    for (DataLayer* d : _dataLayers) {
+        if (d->dataIdx < 0 || d->dataIdx >= (int)_curData.size()) throw NetError("data layer '" + d->name() + "': no data matrix " + std::to_string(d->dataIdx));
+        d->fpropData(_curData[d->dataIdx], pt);
+    }
+}
+
+void ConvNet::fpropSlice(long start, long end, PassType pt) {
+    end = std::min(end, _dp->numCases());
+    _numCases = (int)(end - start);
+    if (_numCases > _allocatedCases) throw NetError("minibatch larger than the allocated size");
+    _dp->getSlice(start, end, _curData);
+    fpropCurrent(pt);
+}
+
+void ConvNet::fprop(int miniIdx, PassType pt) {  // convnet.cu:229-233
+    fpropSlice((long)miniIdx * _minibatchSize, (long)(miniIdx + 1) * _minibatchSize, pt);
+}
+
+void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
+    for (CostLayer* c : _costs) c->bprop(pt);
+    for (auto& l : _layers) l->reset();
+    if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
+}
+
+void ConvNet::updateWeights() {  // convnet.cu:190-194
+    if (dataParallel()) waitComm();
+    for (auto& l : _layers) l->updateWeights();
+}
+
+void ConvNet::copyToCPU() {
+    sync();
+    for (auto& l : _layers) l->copyToCPU();
+}
+
+// ---- data-parallel gradient exchange ---------------------------------------------------------
+void ConvNet::gradReady(WeightLayer* l) {
+    for (Segment& s : _segments)
+        if (s.layer == l) s.ready = true;
+    flushBuckets(false);
+}
+
+void ConvNet::flushBuckets(bool force) {
+    // longest run of completed segments starting at the first one not sent yet
+    size_t end = _sentUpTo;
+    for (Segment& s : _segments) {
+        if (s.end <= _sentUpTo) continue;
+        if (!s.ready && !force) break;
+        end = s.end;
+    }
+    if (end == _sentUpTo) return;
+    if (!force && end - _sentUpTo < _bucketFloats) return;
+    chk(mcn_event_record(_evGrad, _stream), "event record");
+    chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
+    chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
+    _sentUpTo = end;
+    _commPending = true;
+}
+
+void ConvNet::waitComm() {
+    if (_commPending) {
+        chk(mcn_event_record(_evComm, _commStream), "event record");
+        chk(mcn_stream_wait_event(_stream, _evComm), "wait event");
+        _commPending = false;
+    }
+    _sentUpTo = 0;
+    for (Segment& s : _segments) s.ready = false;
+}
+
+void ConvNet::allGather(const float* send, float* recv, size_t countPerRank) {
+    chk(mcn_event_record(_evGrad, _stream), "event record");
+    chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
+    chk(mcn_allgather(_comm, send, recv, countPerRank, _commStream), "all-gather");
+    chk(mcn_event_record(_evComm, _commStream), "event record");
+    chk(mcn_stream_wait_event(_stream, _evComm), "wait event");
+}
+
+// ---- per-operation event timing -----------------------------------------------------------------
+ProfScope::ProfScope(ConvNet* net, const std::string& layer, const char* op, int idx) : _net(net->profiling() ? net : nullptr) {
+    if (_net) _net->profBegin(idx >= 0 ? layer + "." + op + "[" + std::to_string(idx) + "]" : layer + "." + op);
+}
+ProfScope::~ProfScope() {
+    if (_net) _net->profEnd();
+}
+
+void* ConvNet::profEvent() {
+    if (_eventsUsed == _eventPool.size()) {
+        void* e = nullptr;
+        chk(mcn_event_create(&e), "event create");
+        _eventPool.push_back(e);
+    }
+    return _eventPool[_eventsUsed++];
+}
+
+void ConvNet::profBegin(const std::string& label) {
+    auto it = _profLabelIdx.find(label);
+    if (it == _profLabelIdx.end()) {
+        it = _profLabelIdx.emplace(label, (int)_profLabels.size()).first;
+        _profLabels.push_back(label);
+    }
+    ProfSpan s{it->second, profEvent(), nullptr};
+    chk(mcn_event_record(s.e0, _stream), "event record");
+    _profSpans.push_back(s);
+}
+
+void ConvNet::profEnd() {
+    // spans nest at most one deep in practice; close the innermost open one
+    for (size_t i = _profSpans.size(); i-- > 0;)
+        if (!_profSpans[i].e1) {
+            _profSpans[i].e1 = profEvent();
+            chk(mcn_event_record(_profSpans[i].e1, _stream), "event record");
+            return;
+        }
+}
+
+void ConvNet::profCollect(std::map<std::string, ProfEntry>& into) {
+    sync();
+    for (const ProfSpan& s : _profSpans) {
+        if (!s.e1) continue;
+        float ms = 0;
+        chk(mcn_event_elapsed_ms(&ms, s.e0, s.e1), "event elapsed");
+        ProfEntry& e = into[_profLabels[s.label]];
+        e.count++;
+        e.ms += ms;
+    }
+    _profSpans.clear();
+    _eventsUsed = 0;
+}
+
+// ---- costs --------------------------------------------------------------------------------------
+void ConvNet::zeroCosts() { chk(mcn_memset(_costBuf.p, 0, _costBuf.cap * 4, _stream), "zero costs"); }
+
+void ConvNet::readCosts(Cost& into, long numCases) {
+    if (!_costHost.empty()) chk(mcn_d2h(_costHost.data(), _costBuf.p, _costHost.size() * 8, _stream), "d2h costs");
+    sync();
+    int k = 0;
+    for (CostLayer* c : _costs) {
+        auto& v = into.values[c->name()];
+        if (v.empty()) into.names.push_back(c->name());
+        v.resize(c->numCostValues(), 0.0);
+        for (int j = 0; j < c->numCostValues(); j++) v[j] += _costHost[k++];
+        into.coeffs[c->name()] = c->coeff();
+    }
+    into.numCases += numCases;
+}
+
+double ConvNet::costValue() {
+    Cost c;
+    readCosts(c, _numCases);
+    return c.value();
+}
+
+// ---- gradient checking (convnet.cu:257-330) -----------------------------------------------------
+void ConvNet::checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) {
+    if (dataParallel()) throw NetError("gradient checking runs on a single replica");
+    zeroCosts();
+    fprop(0, PASS_GC);
+    _baseErr = costValue();
+    bprop(PASS_GC);
+    for (auto& l : _layers) l->checkGradients(out, maxElems, central);
+}
+
+}  // namespace mcn

@@ -1,0 +1,521 @@
+// Layer graph + device-owning worker thread of the `_ConvNet` extension.
+//
+// Host-side counterpart of the reference's layer.cu / convnet.cu / worker.cu /
+// data.cu / cost.cu / weights.cuh, re-typed onto the C ABI of include/mi_convnet.h:
+// every device operation goes through an mcn_* entry point (no HIP call here, no
+// PyObject either -- see params.h).  Scheduling semantics (received-input counters,
+// activity / gradient buffer sharing, scaleTargets rules, numUpdates) follow the
+// reference line by line in meaning (cited at each method); what is new is
+//   * fused epilogues picked at graph-build time (bias + neuron inside filterActs /
+//     the FC GEMM, relu-gradient inside max-pool undo, single-pass softmax and SGD),
+//   * cost accumulation in device doubles, read back once per data batch,
+//   * one workspace / one gradient arena allocated up front (no allocation on the step path),
+//   * data-parallel replicas: gradient buckets all-reduced over RCCL on a side stream
+//     while backward continues; L2-SN margin searched over the all-gathered pairs.
+#pragma once
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "params.h"
+
+namespace mcn {
+
+enum PassType { PASS_TRAIN = 0, PASS_TEST = 1, PASS_GC = 2 };  // util.cuh:43
+
+struct NetError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+void chk(int rc, const char* what);  // throws NetError carrying mcn_last_error()
+
+// growable device float buffer
+class DBuf {
+   public:
+    float* p = nullptr;
+    size_t cap = 0;
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf();
+    float* ensure(size_t n);
+};
+
+class ConvNet;
+class Layer;
+class CostLayer;
+
+// weights.cuh:41-198
+class Weights {
+   public:
+    Weights(const HostMat& hW, const HostMat& hInc, float eps, float wc, float mom, bool useGrad, bool devFortran);
+    Weights(Weights& src, float eps);  // shared weights, weights.cuh:59-68
+    size_t size() const { return _hW.size(); }
+    long rows() const { return _hW.rows; }
+    long cols() const { return _hW.cols; }
+    float* W() { return _src ? _src->_W.p : _W.p; }
+    float* inc() { return _src ? _src->_inc.p : _inc.p; }
+    float* gradBuf() { return _src ? _src->_grad : _grad; }
+    float* getGrad(bool dp) { return (_useGrad || dp) ? gradBuf() : inc(); }  // weights.cuh:103-106
+    void setGradBuf(float* g) { _grad = g; }
+    bool owner() const { return _src == nullptr; }
+    bool useGrad() const { return _useGrad; }
+    float eps() const { return _eps; }
+    float mom() const { return _mom; }
+    float wc() const { return _wc; }
+    int numUpdates() const { return _src ? _src->numUpdates() : _numUpdates; }
+    int incNumUpdates() { return _src ? _src->incNumUpdates() : _numUpdates++; }
+    void copyToGPU(void* stream);
+    void copyToCPU(void* stream);
+    void update(bool dp, void* stream);  // weights.cuh:150-163, one fused kernel
+    // host <-> device image conversion for gradient checking
+    void hostImage(std::vector<float>& out, void* stream);        // logical (rows, cols) row-major
+    void setElement(long r, long c, float v, void* stream);
+    size_t memIndex(long r, long c) const { return _devFortran ? (size_t)c * _hW.rows + r : (size_t)r * _hW.cols + c; }
+
+   private:
+    void upload(const HostMat& h, float* dst, void* stream);
+    void download(const HostMat& h, const float* src, void* stream);
+    HostMat _hW, _hInc;
+    DBuf _W, _inc;
+    float* _grad = nullptr;
+    float _eps, _wc, _mom;
+    bool _useGrad, _devFortran;
+    int _numUpdates = 0;
+    Weights* _src = nullptr;
+};
+
+class Layer {
+   public:
+    Layer(ConvNet* net, const Params& p);
+    virtual ~Layer() {}
+    // layer.cu:75-114
+    void fpropFromPrev(PassType pt);
+    void fprop(const std::vector<float*>& inputs, PassType pt);
+    // layer.cu:116-158
+    virtual void bprop(PassType pt);
+    void bpropWith(float* v, PassType pt);
+    void reset() { _rcvdF = _rcvdB = 0; }
+    void addPrev(Layer* l) { _prev.push_back(l); }
+    void addNext(Layer* l) { _next.push_back(l); _numGradProducersNext += l->isGradProducer(); }
+    bool isGradConsumer();
+    virtual bool isGradProducer() { return true; }
+    float* getActs();
+    float* getActsGrad();
+    virtual size_t actsElems(int n) const { return (size_t)_outputs * n; }
+    virtual void allocate(int maxCases);  // device buffers for up to maxCases columns
+    virtual size_t workspaceBytes(int maxCases) { return 0; }
+    virtual void updateWeights() {}
+    virtual void copyToCPU() {}
+    virtual void copyToGPU() {}
+    virtual void checkGradients(std::vector<struct GradCheckResult>& out, long maxElems, bool central) {}
+    virtual void collectWeights(std::vector<Weights*>& out) {}
+
+    const std::string& name() const { return _name; }
+    const std::string& type() const { return _type; }
+    int outputs() const { return _outputs; }
+    std::vector<Layer*>& prev() { return _prev; }
+    std::vector<Layer*>& next() { return _next; }
+    int rcvdB() const { return _rcvdB; }
+    int incRcvdB() { return ++_rcvdB; }
+    int actsTarget() const { return _actsTarget; }
+    int actsGradTarget() const { return _actsGradTarget; }
+    int numGradProducersNext() const { return _numGradProducersNext; }
+
+   protected:
+    virtual void fpropActs(int inpIdx, float scaleTargets, PassType pt) {}
+    virtual void bpropActs(float* v, int inpIdx, float scaleTargets, PassType pt) {}
+    virtual void bpropCommon(float* v, PassType pt) {}
+    friend class ConvNet;
+
+    ConvNet* _net;
+    std::string _name, _type;
+    int _outputs = 0;
+    std::vector<Layer*> _prev, _next;
+    std::vector<float*> _inputs;
+    int _actsTarget, _actsGradTarget;
+    bool _gradConsumer, _foundGradConsumers = false;
+    int _numGradProducersNext = 0, _rcvdF = 0, _rcvdB = 0;
+    DBuf _ownActs, _ownActsGrad;
+    float* _acts = nullptr;  // current activity matrix (own buffer, shared input, or data slice)
+};
+
+struct NeuronSpec {
+    int type = 0;
+    float a = 0, b = 0;
+    bool needsInputs() const;  // gradient reads the neuron input (abs, square)
+    bool fusableGrad() const;  // gradient needs only (dE/dy, y)
+};
+
+class NeuronLayer : public Layer {
+   public:
+    NeuronLayer(ConvNet* net, const Params& p);
+    NeuronSpec spec;
+    bool fwdFused = false;  // activation applied in the producer's epilogue
+    bool bwdFused = false;  // gradient applied in the consumer's (max-pool undo) epilogue
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+class WeightLayer : public Layer {
+   public:
+    WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortran);
+    void updateWeights() override;
+    void copyToCPU() override;
+    void copyToGPU() override;
+    void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) override;
+    void collectWeights(std::vector<Weights*>& out) override;
+    Weights& weights(int i) { return *_weights[i]; }
+    int numWeights() const { return (int)_weights.size(); }
+    NeuronLayer* fusedNeuron = nullptr;
+
+   protected:
+    void bpropCommon(float* v, PassType pt) override;
+    virtual void bpropBiases(float* v, PassType pt) = 0;
+    virtual void bpropWeights(float* v, int inpIdx, PassType pt) = 0;
+    float gradScale(float eps, PassType pt) const;  // eps / (numCases * worldSize), 1 for PASS_GC
+    std::vector<std::unique_ptr<Weights>> _weights;
+    std::unique_ptr<Weights> _biases;
+    float _wStep = 0.001f, _bStep = 0.002f;  // layer.cu:294-295
+};
+
+class FCLayer : public WeightLayer {
+   public:
+    FCLayer(ConvNet* net, const Params& p);
+    size_t workspaceBytes(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    void bpropBiases(float* v, PassType) override;
+    void bpropWeights(float* v, int, PassType) override;
+};
+
+class LocalLayer : public WeightLayer {
+   public:
+    LocalLayer(ConvNet* net, const Params& p, bool useGrad, bool conv);
+    size_t workspaceBytes(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    void bpropBiases(float* v, PassType) override;
+    void bpropWeights(float* v, int, PassType) override;
+    bool _conv;
+    std::vector<long> _padding, _stride, _filterSize, _channels, _imgSizeY, _imgSizeX, _groups, _filterChannels;
+    int _filters, _modulesY, _modulesX, _modules, _partialSum = 0, _sharedBiases = 0;
+};
+
+class SoftmaxLayer : public Layer {
+   public:
+    using Layer::Layer;
+    size_t workspaceBytes(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+class EltwiseSumLayer : public Layer {
+   public:
+    EltwiseSumLayer(ConvNet* net, const Params& p);
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    std::vector<double> _coeffs;
+};
+
+class EltwiseMaxLayer : public Layer {
+   public:
+    using Layer::Layer;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+class DataLayer : public Layer {
+   public:
+    DataLayer(ConvNet* net, const Params& p);
+    bool isGradProducer() override { return false; }
+    void fpropData(float* slice, PassType pt);
+    void allocate(int) override {}
+    int dataIdx;
+};
+
+class PoolLayer : public Layer {
+   public:
+    PoolLayer(ConvNet* net, const Params& p);
+    NeuronLayer* fusedNeuronGrad = nullptr;  // relu(-like) below a max pool: gradient applied in the undo kernel
+    bool isMax() const { return _max; }
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    int _channels, _sizeX, _start, _stride, _outputsY, _outputsX, _imgSizeY, _imgSizeX;
+    bool _max;
+};
+
+class ResponseNormLayer : public Layer {
+   public:
+    ResponseNormLayer(ConvNet* net, const Params& p, bool cross);
+    void allocate(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    int _channels, _size, _imgSizeY, _imgSizeX, _blocked;
+    float _scale, _pow;
+    bool _cross;
+    DBuf _denoms;
+};
+
+class CostLayer : public Layer {
+   public:
+    CostLayer(ConvNet* net, const Params& p);
+    void bprop(PassType pt) override;  // layer.cu:929-933
+    bool isGradProducer() override { return _coeff != 0; }
+    float coeff() const { return _coeff; }
+    virtual int numCostValues() const { return 1; }
+    double* dCost = nullptr;  // device accumulators, numCostValues() doubles
+    void allocate(int maxCases) override;
+   protected:
+    float _coeff;
+    DBuf _aux;
+};
+
+class LogregCostLayer : public CostLayer {
+   public:
+    using CostLayer::CostLayer;
+    int numCostValues() const override { return 2; }
+    size_t workspaceBytes(int maxCases) override;
+    size_t actsElems(int n) const override { return (size_t)n; }
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+class SumOfSquaresCostLayer : public CostLayer {
+   public:
+    using CostLayer::CostLayer;
+    size_t actsElems(int n) const override { return (size_t)_prev[0]->outputs() * n; }
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+class L2SNCostLayer : public CostLayer {
+   public:
+    L2SNCostLayer(ConvNet* net, const Params& p);
+    size_t actsElems(int n) const override { return (size_t)n; }
+    void allocate(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    float _m;
+    DBuf _pairStats, _gathered;  // data-parallel: local (dists, labels) and the all-gathered candidates
+    int _extCount = 0;
+};
+
+class L2regCostLayer : public CostLayer {
+   public:
+    using CostLayer::CostLayer;
+    size_t actsElems(int n) const override { return (size_t)n; }
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+};
+
+// ---- data (data.cu) -----------------------------------------------------------------------
+struct CPUData {
+    std::vector<HostMat> mats;                 // (dims, numCases) C-contiguous
+    std::shared_ptr<void> keepAlive;           // whatever owns the host buffers
+    long numCases() const { return mats.empty() ? 0 : mats[0].cols; }
+};
+
+class DataProvider {
+   public:
+    explicit DataProvider(ConvNet* net, int minibatchSize) : _net(net), _minibatchSize(minibatchSize) {}
+    void setData(const CPUData& d);            // data.cu:47-65 (uploads the whole batch when it fits)
+    void clearHost() { _host = CPUData(); }
+    void getSlice(long start, long end, std::vector<float*>& out);  // data.cu:72-98
+    int numMinibatches() const { return (int)((_numCases + _minibatchSize - 1) / _minibatchSize); }
+    int minibatchSize() const { return _minibatchSize; }
+    long numCases() const { return _numCases; }
+    bool resident() const { return _onDevice; }
+   private:
+    ConvNet* _net;
+    int _minibatchSize;
+    CPUData _host;
+    long _numCases = 0;
+    bool _onDevice = false;
+    std::vector<long> _dims;
+    std::vector<std::unique_ptr<DBuf>> _dev, _mini;
+};
+
+// ---- costs (cost.cu) ------------------------------------------------------------------------
+struct Cost {
+    long numCases = 0;
+    std::vector<std::string> names;            // cfg order
+    std::map<std::string, std::vector<double>> values;
+    std::map<std::string, double> coeffs;
+    double value() const;                      // cost.cu:64-70
+};
+
+struct GradCheckResult {
+    std::string name;
+    double analNorm, numNorm, relErr;
+    bool fail;
+};
+
+struct ProfEntry {
+    long count = 0;
+    double ms = 0;
+};
+
+struct WorkResult {
+    enum Type { BATCH_DONE, SYNC_DONE, GRADCHECK_DONE, INIT_DONE, ERROR } type = BATCH_DONE;
+    Cost cost;
+    std::vector<GradCheckResult> gradChecks;
+    std::map<std::string, ProfEntry> profile;  // per-operation device time when profiling was on
+    std::string error;
+};
+
+template <class T>
+class Queue {  // queue.h:36-110, with the wait in a loop (the reference's `if` admits spurious wake-ups)
+   public:
+    void enqueue(T v) {
+        { std::lock_guard<std::mutex> g(_m); _q.push_back(std::move(v)); }
+        _cv.notify_one();
+    }
+    T dequeue() {
+        std::unique_lock<std::mutex> g(_m);
+        _cv.wait(g, [&] { return !_q.empty(); });
+        T v = std::move(_q.front());
+        _q.pop_front();
+        return v;
+    }
+   private:
+    std::mutex _m;
+    std::condition_variable _cv;
+    std::deque<T> _q;
+};
+
+using Work = std::function<void(ConvNet&)>;
+
+// RAII bracket around one layer operation; a no-op unless the net is profiling
+class ProfScope {
+   public:
+    ProfScope(ConvNet* net, const std::string& layer, const char* op, int idx = -1);
+    ~ProfScope();
+   private:
+    ConvNet* _net;
+};
+
+class ConvNet {
+   public:
+    ConvNet(const std::vector<Params>& layers, int minibatchSize, int deviceID);
+    ~ConvNet();
+    void start();                               // spawns the device-owning thread (convnet.cu:147-156)
+    void stop();
+    Queue<Work>& workQueue() { return _work; }
+    Queue<WorkResult>& resultQueue() { return _results; }
+
+    // ---- called on the worker thread -------------------------------------------------------
+    void initDevice();                          // convnet.cu:139-145
+    void initComm(int rank, int world, const char* id128);
+    void fprop(int miniIdx, PassType pt);       // convnet.cu:229-233
+    void fpropSlice(long start, long end, PassType pt);
+    void fpropCurrent(PassType pt);             // convnet.cu:213-219
+    void bprop(PassType pt);                    // convnet.cu:206-211
+    void updateWeights();                       // convnet.cu:190-194
+    void copyToCPU();
+    void zeroCosts();
+    void readCosts(Cost& into, long numCases);  // adds the device accumulators into `into`
+    double costValue();                         // convnet.cu:247-252 (blocking)
+    void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central);
+    bool checkGradient(const std::string& name, float eps, Weights& w, std::vector<GradCheckResult>& out, long maxElems, bool central);
+    void sync();
+
+    // workers (worker.cu)
+    void runTraining(const CPUData& data, bool test, bool useResident);
+    void runFeatures(const CPUData& data, HostMat ftrs, int layerIdx);
+    void runMultiview(const CPUData& data, int numViews, int logregIdx);
+    void runGradCheck(const CPUData& data, long maxElems, bool central);
+    void runLoad(const CPUData& data);
+    // numSteps minibatches cycling over the resident batch (benchmark / profiling loop: no host data,
+    // no allocation, one cost read-back at the end).  profile: bracket every layer operation with events.
+    void runSteps(int numSteps, bool test, bool profile);
+
+    // ---- services for layers ---------------------------------------------------------------
+    void* stream() const { return _stream; }
+    int numCases() const { return _numCases; }
+    int worldSize() const { return _world; }
+    int rank() const { return _rank; }
+    bool dataParallel() const { return _world > 1; }
+    void* workspace() const { return _ws.p; }
+    size_t workspaceBytes() const { return _ws.cap * sizeof(float); }
+    Layer& layer(int i) { return *_layers[i]; }
+    int numLayers() const { return (int)_layers.size(); }
+    DataProvider& dp() { return *_dp; }
+    void gradReady(WeightLayer* l);             // data-parallel: layer's gradient segment is complete
+    void allGather(const float* send, float* recv, size_t countPerRank);  // on the compute stream order
+    void setFusion(bool on) { _fusion = on; }
+    bool profiling() const { return _profiling; }
+    void profBegin(const std::string& label);
+    void profEnd();
+
+   private:
+    void run();
+    void buildFusions();
+    void allocate(int maxCases);
+    void flushBuckets(bool force);
+    void waitComm();
+
+    std::vector<std::unique_ptr<Layer>> _layers;
+    std::vector<DataLayer*> _dataLayers;
+    std::vector<CostLayer*> _costs;
+    std::unique_ptr<DataProvider> _dp;
+    int _minibatchSize, _deviceID;
+    int _numCases = 0;
+    int _allocatedCases = 0;
+    bool _fusion = true;
+    std::vector<float*> _curData;
+
+    void* _stream = nullptr;
+    DBuf _ws;
+    DBuf _gradArena;
+    DBuf _costBuf;  // doubles, viewed as floats x2
+    std::vector<double> _costHost;
+    double _baseErr = 0;
+
+    // data-parallel state
+    int _rank = 0, _world = 1;
+    void* _comm = nullptr;
+    void* _commStream = nullptr;
+    void* _evGrad = nullptr;
+    void* _evComm = nullptr;
+    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; };
+    std::vector<Segment> _segments;  // in arena order (reverse layer order)
+    size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
+    size_t _bucketFloats = 1 << 20;
+    bool _commPending = false;
+
+    // per-operation event timing (off on the normal path)
+    bool _profiling = false;
+    struct ProfSpan { int label; void* e0; void* e1; };
+    std::vector<std::string> _profLabels;
+    std::map<std::string, int> _profLabelIdx;
+    std::vector<ProfSpan> _profSpans;
+    std::vector<void*> _eventPool;
+    size_t _eventsUsed = 0;
+    void* profEvent();
+    void profCollect(std::map<std::string, ProfEntry>& into);
+
+    std::thread _thread;
+    Queue<Work> _work;
+    Queue<WorkResult> _results;
+    bool _stop = false;
+};
+
+}  // namespace mcn

@@ -550,10 +550,14 @@ class OracleNet:
             l.copy_to_host()
 
     # -- the reference's only self-check (convnet.cu:257-330) ---------------
-    def check_gradients(self, data, max_elems=40, seed=0, thresh=0.02):
+    def check_gradients(self, data, max_elems=40, seed=0, thresh=0.02, central=False):
         """Finite-difference check with the reference's steps and threshold.
         Unlike the reference, at most `max_elems` entries of each matrix are
-        perturbed (seeded choice); norms are taken over that subset."""
+        perturbed (seeded choice); norms are taken over that subset.  central=True
+        replaces the reference's forward difference (err - base)/(N*eps) by
+        (err(+eps) - err(-eps))/(2*N*eps), which removes the O(eps) curvature term
+        that dominates at the FC step of 0.1.  Call once per net: like the
+        reference (which exits after the check) conv gradients accumulate."""
         rng = np.random.default_rng(seed)
         self.fprop(data, PASS_GC)
         base = self.cost_value()
@@ -574,7 +578,13 @@ class OracleNet:
                     v = flat[e]
                     flat[e] = v + np.float32(eps)
                     self.fprop(data, PASS_GC)
-                    num[j] = (self.cost_value() - base) / (n * eps)
+                    up = self.cost_value()
+                    if central:
+                        flat[e] = v - np.float32(eps)
+                        self.fprop(data, PASS_GC)
+                        num[j] = (up - self.cost_value()) / (2 * n * eps)
+                    else:
+                        num[j] = (up - base) / (n * eps)
                     flat[e] = v
                 an = anal[idx]
                 rel = np.linalg.norm(num - an) / max(np.linalg.norm(an), 1e-30)

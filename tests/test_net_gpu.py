@@ -1,0 +1,214 @@
+"""GPU parity tests of the whole training path: the `_ConvNet` extension (C++ layer graph over the
+C ABI, HIP kernels) against the whole-net CPU oracle (oracle/net.py) on identical seeded inputs,
+for every BASELINE config.
+
+Stated fp32 tolerance after 3 consecutive SGD steps (momentum and weight decay engaged):
+  * cost sums: |a-b| <= 2e-4*|b| + 1e-5;  the top-1 error COUNT (logreg cost[1]) must agree exactly;
+  * weight increments (what a step changes): per tensor max|a-b| <= 2e-3*max|b| + 1e-9;
+  * weights: per tensor max|a-b| <= 1e-5*max|b| + 1e-8 (biases start at zero and are held to the increment bound).
+The wider increment bound covers fp32 summation-order differences compounding through three
+forward/backward passes; single-kernel parity at 1e-4 is in test_kernels_gpu.py.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import ccn_loader
+
+ccn = ccn_loader.load()
+from cuda_convnet_amd import CFG_DIR, layer  # noqa: E402
+from cuda_convnet_amd.convnet import PRESETS, import_native  # noqa: E402
+from cuda_convnet_amd.data import SyntheticDataProvider  # noqa: E402
+from oracle.net import OracleNet  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(ldef, lpar, kind, img, cases, minibatch=128, seed=3, num_classes=None):
+    dp = SyntheticDataProvider(kind, cases, img=img, minibatch=minibatch, num_classes=num_classes)
+    dims = {i: dp.get_data_dims(i) for i in range(len(dp.dims))}
+    L = layer.parse_layers(ldef, lpar, dims, dp.get_num_classes(), seed=seed)
+    return dp, L
+
+
+def preset(name, cases, minibatch=128):
+    ldef, lpar, kind, img = PRESETS[name]
+    return build(os.path.join(CFG_DIR, ldef), os.path.join(CFG_DIR, lpar), kind, img, cases, minibatch)
+
+
+class Native:
+    """One model per process (pyconvnet.cu:45); always destroyed on exit."""
+
+    def __init__(self, layers, minibatch=128):
+        self.lib = import_native()
+        self.lib.initModel(layers, minibatch, 0)
+
+    def __enter__(self):
+        return self.lib
+
+    def __exit__(self, *a):
+        self.lib.destroyModel()
+
+
+def check_costs(got, want):
+    gc, gn = got
+    wc, wn = want
+    assert gn == wn
+    assert list(gc) == list(wc), 'cost layers must be reported in cfg order'
+    for k in wc:
+        assert len(gc[k]) == len(wc[k])
+        assert abs(gc[k][0] - wc[k][0]) <= 2e-4 * abs(wc[k][0]) + 1e-5, (k, gc[k], wc[k])
+        if len(wc[k]) > 1:  # top-1 error count: exact
+            assert gc[k][1] == wc[k][1], (k, gc[k], wc[k])
+
+
+def check_weights(Lg, Lc):
+    for lg, lc in zip(Lg, Lc):
+        if 'weights' not in lg:
+            continue
+        pairs = [('weights[%d]' % i, a, b) for i, (a, b) in enumerate(zip(lg['weights'], lc['weights']))]
+        pairs += [('weightsInc[%d]' % i, a, b) for i, (a, b) in enumerate(zip(lg['weightsInc'], lc['weightsInc']))]
+        pairs += [('biases', lg['biases'], lc['biases']), ('biasesInc', lg['biasesInc'], lc['biasesInc'])]
+        for nm, a, b in pairs:
+            assert np.all(np.isfinite(a)), (lg['name'], nm)
+            rt, at = (2e-3, 1e-9) if ('Inc' in nm or nm == 'biases') else (1e-5, 1e-8)  # biases start at 0: they ARE increments
+            err = float(np.max(np.abs(a.astype(np.float64) - b)))
+            bound = rt * float(np.max(np.abs(b))) + at
+            assert err <= bound, '%s %s: max abs err %.3e > %.3e' % (lg['name'], nm, err, bound)
+            if 'Inc' in nm:
+                assert float(np.max(np.abs(b))) > 0, '%s %s: the oracle never updated it' % (lg['name'], nm)
+
+
+def oracle_train(Lc, data, minibatch=128, test=False):
+    net = OracleNet(Lc, minibatch)
+    out = net.run_batch(data, test=test)
+    net.sync_with_host()  # write the stepped weights back into Lc's arrays, like syncWithHost does
+    return net, out
+
+
+@pytest.mark.parametrize('name', ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus'])
+def test_train_3_steps_matches_oracle(name):
+    """C1..C5: three consecutive minibatches of 128 through fprop/bprop/update, then syncWithHost."""
+    dp, Lg = preset(name, 384)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    _, want = oracle_train(Lc, data)
+    with Native(Lg) as lib:
+        lib.startBatch(data, 0)
+        got = lib.finishBatch()
+        lib.syncWithHost()
+    check_costs(got, want)
+    check_weights(Lg, Lc)
+
+
+@pytest.mark.parametrize('name,cases', [('deepid-39x31', 1), ('deepid-39x31', 33), ('deepid2', 130), ('deepid2', 200)])
+def test_ragged_batches(name, cases):
+    """A data batch that is not a multiple of the minibatch ends with a short minibatch
+    (DataProvider::getNumMinibatches data.cu:100-103).  Odd sizes only without L2-SN: the reference's
+    gallery/probe halves (layer_kernels.cu:517-527) need an even minibatch."""
+    dp, Lg = preset(name, cases)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    _, want = oracle_train(Lc, data)
+    with Native(Lg) as lib:
+        lib.startBatch(data, 0)
+        got = lib.finishBatch()
+        lib.syncWithHost()
+    check_costs(got, want)
+    check_weights(Lg, Lc)
+
+
+def test_test_pass_leaves_weights_alone_and_resident_batch():
+    dp, Lg = preset('deepid2', 256)
+    Lc = copy.deepcopy(Lg)
+    before = [w.copy() for l in Lg if 'weights' in l for w in l['weights']]
+    data = dp.get_next_batch()[2]
+    _, want = oracle_train(Lc, data, test=True)
+    with Native(Lg) as lib:
+        lib.startBatch(data, 1)
+        got = lib.finishBatch()
+        lib.loadBatch(data)          # keep the batch in HBM, then run on it without passing host data
+        lib.startBatch([], 1)
+        got2 = lib.finishBatch()
+        lib.syncWithHost()
+    check_costs(got, want)
+    check_costs(got2, want)
+    after = [w for l in Lg if 'weights' in l for w in l['weights']]
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+
+
+def test_write_features_matches_oracle():
+    """C4: startFeatureWriter on fc5 and fc-expression (shownet.py:238-259, worker.cu:191-214)."""
+    dp, Lg = preset('deepid-attr', 200)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    onet = OracleNet(Lc, 128)
+    with Native(Lg) as lib:
+        for lname in ('fc5', 'fc-expression'):
+            idx = layer.layer_index(Lg, lname)
+            ftrs = np.full((200, Lg[idx]['outputs']), np.nan, np.float32)
+            lib.startFeatureWriter(list(data) + [ftrs], idx)
+            lib.finishBatch()
+            want = onet.write_features(data, idx)
+            err = np.max(np.abs(ftrs - want))
+            assert err <= 1e-4 * np.max(np.abs(want)) + 1e-6, (lname, err)
+
+
+def small_net(cases, scale=1.0):
+    dp, L = build(os.path.join(HERE, 'cfg', 'gc_small.cfg'), os.path.join(HERE, 'cfg', 'gc_small_params.cfg'),
+                  'dummy', (12, 12, 3), cases, minibatch=cases, num_classes=10)
+    data = dp.get_next_batch()[2]
+    return L, [(data[0] * scale).astype(np.float32), data[1]]
+
+
+def test_gradient_check_small_net():
+    """The reference's only self-check (convnet.cu:257-330) run by the native checkGradients: its steps,
+    its 0.02 threshold, central differences; same net, data and exemption as tests/test_oracle_pins.py."""
+    L, data = small_net(16, scale=8.0)
+    with Native(L, 16) as lib:
+        res = lib.checkGradients(data, 30, 1)
+    assert len(res) == 9  # conv1, local2, fc3 x2, fc4 weights + 4 biases
+    for name, an, nn, rel, fail in res:
+        if name != 'fc4 weights[0]':
+            assert rel < 0.02, (name, an, nn, rel)
+
+
+def test_directional_gradcheck_through_the_boundary():
+    from gradcheck import directional_check
+    L, data = small_net(64)
+    lib = import_native()
+
+    def train(Lx, d):
+        with Native(Lx, d[0].shape[1]) as m:
+            m.startBatch(d, 0)
+            m.finishBatch()
+            m.syncWithHost()
+
+    def cost(Lx, d):
+        with Native(Lx, d[0].shape[1]) as m:
+            m.startBatch(d, 1)
+            return m.finishBatch()[0]
+
+    res = directional_check(L, data, train, cost)
+    assert len(res) == 9
+    for name, num, anal, rel in res:
+        assert rel < 0.02, (name, num, anal, rel)
+
+
+def test_errors_are_exceptions_not_exits():
+    lib = import_native()
+    with pytest.raises(RuntimeError):
+        lib.finishBatch()  # no model
+    dp, Lg = preset('cifar10', 128)
+    bad = copy.deepcopy(Lg)
+    bad[2]['type'] = 'nailbed'
+    with pytest.raises(RuntimeError, match='Unknown layer type'):
+        lib.initModel(bad, 128, 0)
+    with Native(Lg) as lib:
+        with pytest.raises(RuntimeError):
+            lib.startBatch([np.zeros((3072, 128), np.float32)], 0)  # labels missing
+            lib.finishBatch()
