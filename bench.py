@@ -10,8 +10,8 @@ through fprop + bprop (softmax/logreg + L2-SN verification cost) + momentum/weig
 fp32, on the `_ConvNet` extension (C++ layer graph -> C ABI -> hand-written HIP kernels).
 The synthetic data batch is resident in HBM before the timed region starts.  With N > 1 every
 rank is one replica (weak scaling, 128 images per GPU); weight gradients are all-reduced over
-RCCL inside the step.  torch is used only for the launcher plumbing (gloo barrier, broadcast of
-the RCCL unique id, max over ranks); no torch tensor touches the compute path.
+RCCL inside the step.  The launcher plumbing (barrier, broadcast of the RCCL unique id, max over
+ranks) is a loopback TCP group (cuda_convnet_amd/rendezvous.py); torch is not imported.
 
 Prints ONE JSON line on rank 0 (see the README of the driver contract), including
   roofline     -- the operation that takes the most device time in a step, timed live with HIP
@@ -137,6 +137,7 @@ def main():
     ap.add_argument('--resident-minibatches', type=int, default=16)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--force-dp', action='store_true', help='run the replica-exchange path even with one rank (rehearsal)')
     ap.add_argument('--profile-steps', type=int, default=20)
     a = ap.parse_args()
 
@@ -156,12 +157,10 @@ def main():
     from cuda_convnet_amd.convnet import PRESETS, import_native
     from cuda_convnet_amd.data import SyntheticDataProvider
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from cuda_convnet_amd.rendezvous import Group
 
     lib = import_native()
+    group = Group(rank, world)  # loopback control plane; no torch in the GPU processes (see rendezvous.py)
     ldef, lpar, kind, img = PRESETS[a.workload]
     mb = a.minibatch
     cases = mb * a.resident_minibatches
@@ -172,15 +171,12 @@ def main():
     data = dp.get_next_batch()[2]
 
     lib.initModel(layers, mb, local)
-    if world > 1:
-        ids = [lib.commUniqueId() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        lib.initDataParallel(rank, world, ids[0])
+    if world > 1 or a.force_dp:
+        uid = group.broadcast(lib.commUniqueId() if rank == 0 else None)
+        lib.initDataParallel(rank, world, uid, 1 if a.force_dp else 0)
     lib.loadBatch(data)  # inputs resident in HBM from here on
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    barrier = group.barrier
 
     lib.startSteps(a.warmup, 0, 0)
     lib.finishBatch()
@@ -190,11 +186,7 @@ def main():
     costs, ncases = lib.finishBatch()  # blocks until the stream has drained (device synchronised)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = group.max(dt)
     assert ncases == a.steps * mb
     for k, v in costs.items():
         assert all(np.isfinite(v)), ('non-finite cost', k, v)
@@ -228,9 +220,8 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.workload)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.barrier()
+    group.close()
 
 
 if __name__ == '__main__':

@@ -12,6 +12,7 @@
 // instead of exit(1)/assert; checkGradients returns its per-matrix results instead of
 // printing and calling exit(0); the GIL is released while a call blocks.
 #define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <numpy/arrayobject.h>
 
@@ -312,16 +313,16 @@ static PyObject* commUniqueId(PyObject*, PyObject*) {
 }
 
 static PyObject* initDataParallel(PyObject*, PyObject* args) {
-    int rank, world;
+    int rank, world, force = 0;
     const char* id;
     Py_ssize_t idLen;
-    if (!PyArg_ParseTuple(args, "iiy#", &rank, &world, &id, &idLen)) return nullptr;
+    if (!PyArg_ParseTuple(args, "iiy#|i", &rank, &world, &id, &idLen, &force)) return nullptr;
     if (!needModel()) return nullptr;
     if (idLen != 128) { PyErr_SetString(PyExc_ValueError, "initDataParallel: the unique id must be 128 bytes"); return nullptr; }
     std::string ids(id, 128);
     inflight.emplace_back();
-    model->workQueue().enqueue([rank, world, ids](ConvNet& n) {
-        n.initComm(rank, world, ids.data());
+    model->workQueue().enqueue([rank, world, ids, force](ConvNet& n) {
+        n.initComm(rank, world, ids.data(), force != 0);
         WorkResult r;
         r.type = WorkResult::SYNC_DONE;
         n.resultQueue().enqueue(std::move(r));
@@ -343,7 +344,7 @@ static PyMethodDef methods[] = {
     {"startSteps", startSteps, METH_VARARGS, "startSteps(numSteps, test=0, profile=0): minibatch steps cycling over the resident batch (asynchronous)"},
     {"getProfile", getProfile, METH_NOARGS, "getProfile() -> {operation: (count, total device ms)} of the last profiled startSteps"},
     {"commUniqueId", commUniqueId, METH_NOARGS, "commUniqueId() -> 128 bytes"},
-    {"initDataParallel", initDataParallel, METH_VARARGS, "initDataParallel(rank, worldSize, uniqueId)"},
+    {"initDataParallel", initDataParallel, METH_VARARGS, "initDataParallel(rank, worldSize, uniqueId, force=0)"},
     {"destroyModel", destroyModel, METH_NOARGS, "destroyModel()"},
     {nullptr, nullptr, 0, nullptr}};
 

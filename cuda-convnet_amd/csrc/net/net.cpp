@@ -752,6 +752,11 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
 
 ConvNet::~ConvNet() {
     stop();
+    if (_comm) mcn_comm_destroy(_comm);
+    if (_commStream) mcn_stream_destroy(_commStream);
+    if (_evGrad) mcn_event_destroy(_evGrad);
+    if (_evComm) mcn_event_destroy(_evComm);
+    if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
 }
 
@@ -867,11 +872,13 @@ void ConvNet::allocate(int maxCases) {
     chk(mcn_stream_sync(_stream), "sync");
 }
 
-void ConvNet::initComm(int rank, int world, const char* id128) {
+void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     if (world < 1 || rank < 0 || rank >= world) throw NetError("bad data-parallel rank / world size");
+    if (_dpOn) throw NetError("data-parallel group already initialised");
     _rank = rank;
     _world = world;
-    if (world > 1) {
+    _dpOn = world > 1 || force;
+    if (_dpOn) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
         chk(mcn_stream_create(&_commStream), "comm stream");
         chk(mcn_event_create(&_evGrad), "event");

@@ -423,7 +423,7 @@ class ConvNet {
 
     // ---- called on the worker thread -------------------------------------------------------
     void initDevice();                          // convnet.cu:139-145
-    void initComm(int rank, int world, const char* id128);
+    void initComm(int rank, int world, const char* id128, bool force);  // force: run the exchange path even with one rank
     void fprop(int miniIdx, PassType pt);       // convnet.cu:229-233
     void fpropSlice(long start, long end, PassType pt);
     void fpropCurrent(PassType pt);             // convnet.cu:213-219
@@ -452,7 +452,7 @@ class ConvNet {
     int numCases() const { return _numCases; }
     int worldSize() const { return _world; }
     int rank() const { return _rank; }
-    bool dataParallel() const { return _world > 1; }
+    bool dataParallel() const { return _dpOn; }
     void* workspace() const { return _ws.p; }
     size_t workspaceBytes() const { return _ws.cap * sizeof(float); }
     Layer& layer(int i) { return *_layers[i]; }
@@ -491,6 +491,7 @@ class ConvNet {
 
     // data-parallel state
     int _rank = 0, _world = 1;
+    bool _dpOn = false;
     void* _comm = nullptr;
     void* _commStream = nullptr;
     void* _evGrad = nullptr;

@@ -104,6 +104,24 @@ def test_train_3_steps_matches_oracle(name):
     check_weights(Lg, Lc)
 
 
+@pytest.mark.parametrize('name', ['deepid2', 'cifar10'])
+def test_data_parallel_path_single_rank(name):
+    """The replica-exchange path (raw gradients into the arena, bucketed RCCL all-reduce on the side stream,
+    momentum folded after the exchange, L2-SN margin over all-gathered pairs) with a one-rank communicator
+    must reproduce the single-GPU result; the N > 1 algorithm is covered on CPU in test_dp_gloo.py."""
+    dp, Lg = preset(name, 384)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    _, want = oracle_train(Lc, data)
+    with Native(Lg) as lib:
+        lib.initDataParallel(0, 1, lib.commUniqueId(), 1)
+        lib.startBatch(data, 0)
+        got = lib.finishBatch()
+        lib.syncWithHost()
+    check_costs(got, want)
+    check_weights(Lg, Lc)
+
+
 @pytest.mark.parametrize('name,cases', [('deepid-39x31', 1), ('deepid-39x31', 33), ('deepid2', 130), ('deepid2', 200)])
 def test_ragged_batches(name, cases):
     """A data batch that is not a multiple of the minibatch ends with a short minibatch
