@@ -38,12 +38,16 @@ class Weights:
     def _mem(self, a):
         return np.ascontiguousarray(a.T) if self.fortran else np.ascontiguousarray(a)
 
-    def get_grad(self):
-        return self.grad if self.use_grad else self.inc
+    def get_grad(self, dp=False):
+        if dp and self.grad is None:
+            self.grad = np.zeros_like(self.W)
+        return self.grad if (self.use_grad or dp) else self.inc
 
-    def update(self):
+    def update(self, comm=None):
         if self.eps > 0:
-            K.sgd_update(self.W, self.inc, self.grad, self.mom, self.wc, self.eps, self.use_grad)
+            if comm is not None:  # data-parallel: raw scaled gradients are summed over the replicas first
+                comm.all_reduce(self.get_grad(True))
+            K.sgd_update(self.W, self.inc, self.grad, self.mom, self.wc, self.eps, self.use_grad or comm is not None)
             self.num_updates = 0
 
     def copy_to_host(self):
@@ -197,10 +201,14 @@ class WeightLayer(Layer):
                 self.bprop_weights(v, i, pt)
                 w.num_updates += 1
 
+    def grad_scale(self, eps, pt):
+        """eps / (numCases * replicas); 1 for gradient checking (layer.cu:370,379)."""
+        return 1.0 if pt == PASS_GC else eps / (self.net.num_cases * self.net.world)
+
     def update_weights(self):
         for w in self.weights:
-            w.update()
-        self.biases.update()
+            w.update(self.net.comm)
+        self.biases.update(self.net.comm)
 
     def copy_to_host(self):
         for w in self.weights:
@@ -226,15 +234,18 @@ class FCLayer(WeightLayer):
 
     def bprop_biases(self, v, pt):  # layer.cu:368-372
         n = self.net.num_cases
-        sc = 1.0 if pt == PASS_GC else self.biases.eps / n
-        K.add_sum(self.biases.grad, v, self.outputs, n, 1, 0.0, sc)
+        K.add_sum(self.biases.grad, v, self.outputs, n, 1, 0.0, self.grad_scale(self.biases.eps, pt))
 
     def bprop_weights(self, v, i, pt):  # layer.cu:374-384
         n, I = self.net.num_cases, self.prev[i].outputs
         w = self.weights[i]
-        scale_inc = (1.0 if (w.num_updates == 0 and pt != PASS_GC) else 0.0) * w.mom
-        scale_grad = 1.0 if pt == PASS_GC else w.eps / n
-        K.gemm(v, self.prev[i].acts, self.outputs, I, n, tb=True, alpha=scale_grad, beta=scale_inc, Cmat=w.inc)
+        dp = self.net.comm is not None
+        if dp:  # raw gradient; momentum is folded in after the exchange (algebraically identical)
+            scale_inc = 1.0 if w.num_updates > 0 else 0.0
+        else:
+            scale_inc = (1.0 if (w.num_updates == 0 and pt != PASS_GC) else 0.0) * w.mom
+        K.gemm(v, self.prev[i].acts, self.outputs, I, n, tb=True, alpha=self.grad_scale(w.eps, pt), beta=scale_inc,
+               Cmat=w.get_grad(dp))
 
 
 class LocalLayer(WeightLayer):
@@ -260,7 +271,7 @@ class LocalLayer(WeightLayer):
 
     def bprop_biases(self, v, pt):  # layer.cu:464-474, :545-549
         d, n = self.d, self.net.num_cases
-        sc = 1.0 if pt == PASS_GC else self.biases.eps / n
+        sc = self.grad_scale(self.biases.eps, pt)
         if self.conv and d['sharedBiases']:
             K.add_sum(self.biases.grad, v, d['filters'], d['modules'] * n, 1, 0.0, sc)
         else:
@@ -279,7 +290,7 @@ class ConvLayer(LocalLayer):
         d, n = self.d, self.net.num_cases
         w = self.weights[i]
         ps = d['partialSum']
-        scale_w = 1.0 if pt == PASS_GC else w.eps / n
+        scale_w = self.grad_scale(w.eps, pt)
         if ps > 0:
             tmp = K.weight_acts(self.prev[i].acts, v, n, partial_sum=ps, sT=0.0, sO=scale_w, conv=True, **self.geo(i))
             rows = d['modules'] // ps
@@ -296,9 +307,13 @@ class LocalUnsharedLayer(LocalLayer):
     def bprop_weights(self, v, i, pt):  # layer.cu:551-564
         n = self.net.num_cases
         w = self.weights[i]
-        scale_inc = (1.0 if (pt != PASS_GC and w.num_updates == 0) else 0.0) * w.mom
-        scale_w = 1.0 if pt == PASS_GC else w.eps / n
-        K.weight_acts(self.prev[i].acts, v, n, targets=w.inc, sT=scale_inc, sO=scale_w, conv=False, **self.geo(i))
+        dp = self.net.comm is not None
+        if dp:
+            scale_inc = 1.0 if w.num_updates > 0 else 0.0
+        else:
+            scale_inc = (1.0 if (pt != PASS_GC and w.num_updates == 0) else 0.0) * w.mom
+        K.weight_acts(self.prev[i].acts, v, n, targets=w.get_grad(dp), sT=scale_inc, sO=self.grad_scale(w.eps, pt), conv=False,
+                      **self.geo(i))
 
 
 class SoftmaxLayer(Layer):
@@ -437,15 +452,21 @@ class L2SNCostLayer(CostLayer):
     def fprop_acts(self, i, st, pt):  # layer.cu:1060-1071
         if i == 0:
             labels, data = self.inputs
+            self.m_eff = self.d['m']
+            if self.net.comm is not None and self.m_eff < 0:
+                # data-parallel: the data-dependent margin is searched over the pairs of ALL replicas
+                # (rank-major order == the pair order of the single-GPU global minibatch)
+                _, _, _, dists, plab = K.l2sn_cost(labels, data, data.shape[0], self.net.num_cases, 1.0)
+                self.m_eff, _ = K.l2sn_optimal_thr(self.net.comm.all_gather(dists), self.net.comm.all_gather(plab))
             out, self.m_used, self.m_idx, self.dists, self.pair_labels = K.l2sn_cost(
-                labels, data, data.shape[0], self.net.num_cases, self.d['m'])
+                labels, data, data.shape[0], self.net.num_cases, self.m_eff)
             self.acts = out
             self.costv = [K.sum_all(out)]
 
     def bprop_acts(self, v, i, st, pt):  # layer.cu:1073-1082
         if i == 1:
             data = self.prev[1].acts
-            K.l2sn_grad(self.prev[0].acts, data, data.shape[0], self.net.num_cases, self.coeff, self.d['m'],
+            K.l2sn_grad(self.prev[0].acts, data, data.shape[0], self.net.num_cases, self.coeff, self.m_eff,
                         target=self.prev[1].get_acts_grad(), add=st == 1)
 
 
@@ -474,8 +495,13 @@ _TYPES = {'fc': FCLayer, 'conv': ConvLayer, 'local': LocalUnsharedLayer, 'pool':
 class OracleNet:
     """ConvNet (convnet.cu:44-81) + TrainingWorker (worker.cu:88-102) on the CPU oracle."""
 
-    def __init__(self, layers, minibatch_size=128):
+    def __init__(self, layers, minibatch_size=128, comm=None):
+        """comm: None, or a replica group with .world, .all_reduce(array) (in-place sum) and
+        .all_gather(array) (rank-major concatenation) -- the data-parallel algorithm of the product
+         restated on the CPU."""
         self.minibatch_size = minibatch_size
+        self.comm = comm
+        self.world = comm.world if comm is not None else 1
         self.layers, self.costs, self.data_layers = [], [], []
         for d in layers:
             l = _TYPES[d['type']](self, d)

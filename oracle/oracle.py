@@ -230,6 +230,14 @@ def l2sn_cost(idens, data, D, N, m=-1.0):
     return out, float(m_used), idx.value, dists, labels
 
 
+def l2sn_optimal_thr(dists, labels):
+    """getOptimalThr (layer_kernels.cu:482-498) over the given candidates -> (m, index)."""
+    dists, labels = _c(dists).reshape(-1), _c(labels).reshape(-1)
+    idx = C.c_int(-1)
+    m = lib().orc_l2sn_optimal_thr(_p(dists), _p(labels), dists.size, C.byref(idx))
+    return float(m), idx.value
+
+
 def l2sn_grad(idens, data, D, N, coeff, m=-1.0, target=None, add=False):
     if target is None:
         target = np.zeros((D, N), np.float32)
