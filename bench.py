@@ -42,6 +42,11 @@ def op_work(layers, label, N):
     if '[' in op:
         op, i = op[:-1].split('[')
         idx = int(i)
+    if lname == 'net' and op == 'update':  # every matrix in one launch
+        nW = sum(w.size for x in layers if 'weights' in x for w in x['weights'])
+        nConv = sum(w.size for x in layers if x['type'] == 'conv' for w in x['weights'])
+        nB = sum(x['biases'].size for x in layers if 'weights' in x)
+        return 3.0 * nW, 4.0 * (4 * nW + nConv + 5 * nB), 'hbm'
     l = next(x for x in layers if x['name'] == lname)
     t = l['type']
     if t in ('conv', 'local'):

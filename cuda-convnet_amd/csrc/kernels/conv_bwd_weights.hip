@@ -8,8 +8,9 @@
 // MFMA roles: A[row=k][kk=n] from image rows, B[kk=n][col=f] from hidActs rows.
 // Both operands are contiguous along the REDUCTION index n, whose order inside
 // an MFMA chain is free as long as A and B agree: every lane reads 4 consecutive
-// images with one 16-byte load and uses component t in step t.  One wave owns
-// 16*KV weight rows x 16*FV filters for one module chunk; no LDS transposes.
+// images with one 16-byte load and uses component t in step t.  One 4-wave block owns
+// 16*KV weight rows x 16*FV filters for one module chunk: its waves take the chunk's
+// modules round-robin and their accumulators are summed through LDS in a fixed order.
 #include "common.h"
 
 struct BwdWParams {
@@ -40,8 +41,7 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int kt = blockIdx.y * 4 + wave;
-    if (kt >= ktiles) return;
+    const int kt = blockIdx.y;
     const int chunk = blockIdx.x;
     const int f0 = blockIdx.z * (16 * FV);
     const int grp = f0 / fpg;
@@ -63,8 +63,12 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
     const float* ig = p.images + (ptrdiff_t)grp * fc * imgPixels * p.imgStride + 4 * kk;
     const float* hg = p.hidActs + (size_t)(f0 + j) * M * p.N + 4 * kk;
 
+    // the four waves of the block take the chunk's modules round-robin and are summed through LDS below
     const int mBeg = chunk * p.modulesPerChunk, mEnd = min(M, mBeg + p.modulesPerChunk);
-    for (int m = mBeg; m < mEnd; m++) {
+    // (chunks of fewer than four modules -- the unshared local layers -- split the images instead)
+    const bool splitN = p.modulesPerChunk < 4;
+    const int mStep = splitN ? 1 : 4, nStep = splitN ? 64 : 16;
+    for (int m = mBeg + (splitN ? 0 : wave); m < mEnd; m += mStep) {
         const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
         const float* arow[KV];
         bool ainb[KV];
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
             arow[v] = ig + ((ptrdiff_t)off[v] + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride;
         }
         const float* hm = hg + (size_t)m * p.N;
-        for (int nb = 0; nb < p.N; nb += 16) {
+        for (int nb = splitN ? 16 * wave : 0; nb < p.N; nb += nStep) {
             const int n = nb + 4 * kk;
             f32x4 a[KV], b[FV];
 #pragma unroll
@@ -106,6 +110,28 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
         }
     }
 
+    // fixed-order sum of the four waves' accumulators: wave 0 + wave 1 + wave 2 + wave 3
+    __syncthreads();  // everyone is done with the decode table
+    float* red = reinterpret_cast<float*>(tbl);
+    for (int w = 1; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int v = 0; v < KV; v++)
+#pragma unroll
+                for (int u = 0; u < FV; u++)
+                    *reinterpret_cast<f32x4*>(red + ((v * FV + u) * 64 + lane) * 4) = acc[v][u];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int v = 0; v < KV; v++)
+#pragma unroll
+                for (int u = 0; u < FV; u++) acc[v][u] += *reinterpret_cast<const f32x4*>(red + ((v * FV + u) * 64 + lane) * 4);
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+
     // D row 4kk+r of tile v <-> weight row kb+16v+4kk+r ; col j of tile u <-> filter f0+16u+j
 #pragma unroll
     for (int v = 0; v < KV; v++)
@@ -123,21 +149,31 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
 }
 
 // column sums of the (chunks x cols) partials in a fixed order: grad = sT*grad + sum
+// One block per 16 columns: thread (r = tid/16, c = tid%16) sums rows r, r+16, ... in four interleaved
+// running sums, then the 16 row groups are combined through LDS in a fixed tree.
 __global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__ part, float* __restrict__ grad,
                                                        int chunks, int cols, float sT) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float sh[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < chunks; r += 4) {
-        s0 += part[(size_t)r * cols + c];
-        s1 += part[(size_t)(r + 1) * cols + c];
-        s2 += part[(size_t)(r + 2) * cols + c];
-        s3 += part[(size_t)(r + 3) * cols + c];
+    if (c < cols) {
+        int r = rg;
+        for (; r + 48 < chunks; r += 64) {
+            s0 += part[(size_t)r * cols + c];
+            s1 += part[(size_t)(r + 16) * cols + c];
+            s2 += part[(size_t)(r + 32) * cols + c];
+            s3 += part[(size_t)(r + 48) * cols + c];
+        }
+        for (; r < chunks; r += 16) s0 += part[(size_t)r * cols + c];
     }
-    for (; r < chunks; r++) s0 += part[(size_t)r * cols + c];
-    const float s = (s0 + s1) + (s2 + s3);
-    grad[c] = sT != 0.f ? sT * grad[c] + s : s;
+    sh[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int o = 8; o > 0; o >>= 1) {
+        if (rg < o) sh[rg][cl] += sh[rg + o][cl];
+        __syncthreads();
+    }
+    if (rg == 0 && c < cols) grad[c] = sT != 0.f ? sT * grad[c] + sh[0][cl] : sh[0][cl];
 }
 
 template <int KV, int FV>
@@ -181,13 +217,14 @@ static int weight_acts_launch(const float* images, const float* hidActs, float* 
     int FV = ftiles % 2 == 0 ? 2 : 1;
     const int kt16 = divup(K, 16);
     int KV = kt16 >= 3 ? 3 : kt16;
-    auto waves = [&](int kv, int fv) { return (long)chunks * divup(K, 16 * kv) * (F / (16 * fv)); };
-    while (waves(KV, FV) < 1024 && KV > 1) KV--;
-    if (waves(KV, FV) < 1024 && FV == 2) FV = 1;
+    auto blocks = [&](int kv, int fv) { return (long)chunks * divup(K, 16 * kv) * (F / (16 * fv)); };
+    while (blocks(KV, FV) < 512 && KV > 1) KV--;
+    if (blocks(KV, FV) < 512 && FV == 2) FV = 1;
     const int ktiles = divup(K, 16 * KV);
-    dim3 grid(chunks, divup(ktiles, 4), F / (16 * FV));
+    dim3 grid(chunks, ktiles, F / (16 * FV));
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "weightActs: grid too large");
-    const size_t lds = (size_t)ktiles * 16 * KV * 8;
+    size_t lds = (size_t)ktiles * 16 * KV * 8;  // decode table, reused for the cross-wave reduction
+    if (lds < (size_t)KV * FV * 64 * 16) lds = (size_t)KV * FV * 64 * 16;
     MCN_REQUIRE(lds <= 64 * 1024, "weightActs: filter too large for the decode table (%zu bytes)", lds);
     if (KV == 3 && FV == 2) launch_bw2<3, 2>(p, grid, lds, vecn, s);
     else if (KV == 3) launch_bw2<3, 1>(p, grid, lds, vecn, s);
@@ -229,7 +266,8 @@ MCN_API int mcn_local_weight_acts(const float* images, const float* hidActs, flo
 // second pass negligible
 static int reduced_modules_per_chunk(int M, int K, int F) {
     const long tilesPerChunk = (long)divup(K, 48) * (F / 16);
-    long want = divup(2048, (int)(tilesPerChunk > 0 ? tilesPerChunk : 1));  // chunks wanted
+    long want = divup(1024, (int)(tilesPerChunk > 0 ? tilesPerChunk : 1));  // chunks wanted (a chunk is a 4-wave block per tile)
+    if (want > M / 8) want = M / 8 > 0 ? M / 8 : 1;                         // at least two modules per wave
     if (want < 1) want = 1;
     if (want > M) want = M;
     return divup(M, (int)want);
@@ -263,7 +301,7 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
                             mpc, 0.f, scaleOutput, (hipStream_t)stream);
     if (rc) return rc;
     const int cols = K * numFilters;
-    hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 256)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, grad, chunks, cols, scaleTargets);
     return MCN_LAUNCH_CHECK("convWeightActsReduced");
 }

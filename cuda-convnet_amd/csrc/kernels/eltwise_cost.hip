@@ -7,6 +7,7 @@
 // All are HBM- or latency-bound; they use 16-byte accesses along the contiguous
 // dimension and fixed-order reductions (deterministic results).
 #include <algorithm>
+#include <vector>
 #include "common.h"
 
 // No multiply-add contraction in this file: the reference runs every NVMatrix op of the
@@ -259,41 +260,88 @@ MCN_API int mcn_transpose(const float* src, float* dst, int rows, int cols, void
 
 // ---------------------------------------------------------------- softmax
 // x, p are (numOut, numCases) row-major; the softmax runs down each column.  Stage 1: block
-// (caseTile of 64, rowChunk) computes per-column (max, sum exp(x - max)) over its rows; stage 2
-// merges the chunk partials in chunk order and writes p = exp(x - M) / S.
-#define SM_ROWS 256  // rows per chunk
+// (caseTile of 64, rowChunk of SM_ROWS) computes per-column (max, sum exp(x - max)) over its rows;
+// stage 2: every block merges the chunk partials of its 64 columns (same fixed order in every block, so
+// all rows of a column see bit-identical M and S) and writes p = exp(x - M) / S for its own rows.
+#define SM_ROWS 64  // rows per chunk: K = 10575 -> 166 chunks x 2 case tiles = 332 blocks
 __global__ __launch_bounds__(256) void k_softmax_partial(const float* __restrict__ x, float* __restrict__ part, int numOut, int numCases, int chunks) {
     __shared__ float shm[4][64], shs[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
+    const int l = threadIdx.x & 63, col = blockIdx.x * 64 + l, rl = threadIdx.x >> 6, chunk = blockIdx.y;
     const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
+    float v[SM_ROWS / 4];
     float m = -INFINITY, s = 0.f;
-    if (col < numCases) {
-        for (int r = r0 + rl; r < r1; r += 4) m = fmaxf(m, x[(size_t)r * numCases + col]);
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 4; i++) {
+        const int r = r0 + rl + 4 * i;
+        v[i] = (col < numCases && r < r1) ? x[(size_t)r * numCases + col] : -INFINITY;
+        m = fmaxf(m, v[i]);
     }
-    shm[rl][threadIdx.x & 63] = m;
+    shm[rl][l] = m;
     __syncthreads();
-    m = fmaxf(fmaxf(shm[0][threadIdx.x & 63], shm[1][threadIdx.x & 63]), fmaxf(shm[2][threadIdx.x & 63], shm[3][threadIdx.x & 63]));
-    if (col < numCases) {
-        for (int r = r0 + rl; r < r1; r += 4) s += expf(x[(size_t)r * numCases + col] - m);
-    }
-    shs[rl][threadIdx.x & 63] = s;
+    m = fmaxf(fmaxf(shm[0][l], shm[1][l]), fmaxf(shm[2][l], shm[3][l]));
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 4; i++) s += v[i] == -INFINITY ? 0.f : expf(v[i] - m);
+    shs[rl][l] = s;
     __syncthreads();
     if (rl == 0 && col < numCases) {
-        s = (shs[0][threadIdx.x] + shs[1][threadIdx.x]) + (shs[2][threadIdx.x] + shs[3][threadIdx.x]);
+        s = (shs[0][l] + shs[1][l]) + (shs[2][l] + shs[3][l]);
         part[((size_t)chunk * numCases + col) * 2] = m;
         part[((size_t)chunk * numCases + col) * 2 + 1] = s;
     }
 }
+// 16 columns x 16 merge lanes per block: lane g merges chunks g, g+16, ... (one batch of independent loads),
+// the 16 lanes are combined through LDS in a fixed order, then the block writes its 64 rows x 16 columns.
+#define SMF_COLS 16
+#define SMF_MAXB 16  // chunks per merge lane held in registers per batch
+__device__ __forceinline__ void softmax_merge16(const f32x2* pp, int numCases, int chunks, int col, bool live, int g, int cl,
+                                                float (*shm)[SMF_COLS], float (*shs)[SMF_COLS], float& M, float& S) {
+    M = -INFINITY;
+    S = 0.f;
+    float lm = -INFINITY, ls = 0.f;
+    for (int c0 = g; c0 < chunks; c0 += 16 * SMF_MAXB) {
+        f32x2 v[SMF_MAXB];
+#pragma unroll
+        for (int u = 0; u < SMF_MAXB; u++) {
+            const int c = c0 + 16 * u;
+            v[u] = (live && c < chunks) ? pp[(size_t)c * numCases + col] : (f32x2){-INFINITY, 0.f};
+        }
+        float bm = lm;
+#pragma unroll
+        for (int u = 0; u < SMF_MAXB; u++) bm = fmaxf(bm, v[u][0]);
+        float bs = (lm == -INFINITY) ? 0.f : ls * expf(lm - bm);
+#pragma unroll
+        for (int u = 0; u < SMF_MAXB; u++) bs += (v[u][0] == -INFINITY) ? 0.f : v[u][1] * expf(v[u][0] - bm);
+        lm = bm;
+        ls = bs;
+    }
+    shm[g][cl] = lm;
+    shs[g][cl] = ls;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) M = fmaxf(M, shm[k][cl]);
+#pragma unroll
+    for (int k = 0; k < 16; k++) S += (shm[k][cl] == -INFINITY) ? 0.f : shs[k][cl] * expf(shm[k][cl] - M);
+}
 __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
                                                        int numOut, int numCases, int chunks) {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, chunk = blockIdx.y;
-    if (col >= numCases) return;
-    float M = -INFINITY;
-    for (int c = 0; c < chunks; c++) M = fmaxf(M, part[((size_t)c * numCases + col) * 2]);
-    float S = 0.f;
-    for (int c = 0; c < chunks; c++) S += part[((size_t)c * numCases + col) * 2 + 1] * expf(part[((size_t)c * numCases + col) * 2] - M);
-    const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
-    for (int r = r0 + rl; r < r1; r += 4) p[(size_t)r * numCases + col] = expf(x[(size_t)r * numCases + col] - M) / S;
+    __shared__ float shm[16][SMF_COLS], shs[16][SMF_COLS];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, col = blockIdx.x * SMF_COLS + cl, chunk = blockIdx.y;
+    const bool live = col < numCases;
+    float M, S;
+    softmax_merge16(reinterpret_cast<const f32x2*>(part), numCases, chunks, col, live, g, cl, shm, shs, M, S);
+    if (!live) return;
+    const int r0 = chunk * SM_ROWS;
+    float v[SM_ROWS / 16];
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 16; i++) {
+        const int r = r0 + g + 16 * i;
+        v[i] = r < numOut ? x[(size_t)r * numCases + col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 16; i++) {
+        const int r = r0 + g + 16 * i;
+        if (r < numOut) p[(size_t)r * numCases + col] = expf(v[i] - M) / S;
+    }
 }
 MCN_API size_t mcn_softmax_workspace_bytes(int numOut, int numCases) {
     return (size_t)divup(numOut, SM_ROWS) * numCases * 2 * sizeof(float);
@@ -310,7 +358,8 @@ MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(divup(numCases, 64), chunks);
     hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
-    hipLaunchKernelGGL(k_softmax_final, grid, dim3(256), 0, s, x, probs, (const float*)workspace, numOut, numCases, chunks);
+    hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), chunks), dim3(256), 0, s, x, probs, (const float*)workspace, numOut,
+                       numCases, chunks);
     return MCN_LAUNCH_CHECK("softmax");
 }
 
@@ -318,63 +367,85 @@ MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, 
 // Stage 1: per (case, rowChunk): max prob and how many entries equal it.  Stage 2 (one block):
 // merge chunks, read p[label], write logprob / correctProbs (kLogregCost layer_kernels.cu:59-92)
 // and accumulate the two cost scalars in double.
+__device__ __forceinline__ void maxcnt_merge(float& m, int& cnt, float pm, int pc) {
+    if (pm > m) { m = pm; cnt = pc; } else if (pm == m) cnt += pc;
+}
 __global__ __launch_bounds__(256) void k_logreg_partial(const float* __restrict__ probs, float* __restrict__ part, int numOut, int numCases) {
     __shared__ float shm[4][64];
     __shared__ int shc[4][64];
     const int l = threadIdx.x & 63, col = blockIdx.x * 64 + l, rl = threadIdx.x >> 6, chunk = blockIdx.y;
     const int r0 = chunk * SM_ROWS, r1 = min(numOut, r0 + SM_ROWS);
+    float v[SM_ROWS / 4];
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 4; i++) {
+        const int r = r0 + rl + 4 * i;
+        v[i] = (col < numCases && r < r1) ? probs[(size_t)r * numCases + col] : -INFINITY;
+    }
     float m = -INFINITY;
     int cnt = 0;
-    if (col < numCases) {
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const float v = probs[(size_t)r * numCases + col];
-            if (v > m) { m = v; cnt = 1; } else if (v == m) cnt++;
-        }
-    }
+#pragma unroll
+    for (int i = 0; i < SM_ROWS / 4; i++)
+        if (v[i] != -INFINITY) maxcnt_merge(m, cnt, v[i], 1);
     shm[rl][l] = m;
     shc[rl][l] = cnt;
     __syncthreads();
     if (rl == 0 && col < numCases) {
-        for (int k = 1; k < 4; k++) {
-            if (shm[k][l] > m) { m = shm[k][l]; cnt = shc[k][l]; } else if (shm[k][l] == m) cnt += shc[k][l];
-        }
+        for (int k = 1; k < 4; k++) maxcnt_merge(m, cnt, shm[k][l], shc[k][l]);
         part[((size_t)chunk * numCases + col) * 2] = m;
         part[((size_t)chunk * numCases + col) * 2 + 1] = (float)cnt;
     }
 }
+// 16 columns x 16 merge lanes per block (see k_softmax_final); each block adds its columns' cost into the two
+// double accumulators with atomics (at most numCases/16 adds per call; order affects the 16th digit only).
 __global__ __launch_bounds__(256) void k_logreg_final(const float* __restrict__ labels, const float* __restrict__ probs,
                                                       const float* __restrict__ part, float* __restrict__ labelLogProbs,
                                                       float* __restrict__ correctProbs, int numOut, int numCases, int chunks,
                                                       double* costOut) {
-    __shared__ double sh0[256], sh1[256];
-    double a0 = 0, a1 = 0;
-    for (int col = threadIdx.x; col < numCases; col += 256) {
-        float m = -INFINITY;
-        int cnt = 0;
-        for (int c = 0; c < chunks; c++) {
-            const float pm = part[((size_t)c * numCases + col) * 2];
-            const int pc = (int)part[((size_t)c * numCases + col) * 2 + 1];
-            if (pm > m) { m = pm; cnt = pc; } else if (pm == m) cnt += pc;
+    __shared__ float shm[16][SMF_COLS];
+    __shared__ int shc[16][SMF_COLS];
+    __shared__ double sh0[SMF_COLS], sh1[SMF_COLS];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, col = blockIdx.x * SMF_COLS + cl;
+    const bool live = col < numCases;
+    const f32x2* pp = reinterpret_cast<const f32x2*>(part);
+    float m = -INFINITY;
+    int cnt = 0;
+    for (int c0 = g; c0 < chunks; c0 += 16 * SMF_MAXB) {
+        f32x2 v[SMF_MAXB];
+#pragma unroll
+        for (int u = 0; u < SMF_MAXB; u++) {
+            const int c = c0 + 16 * u;
+            v[u] = (live && c < chunks) ? pp[(size_t)c * numCases + col] : (f32x2){-INFINITY, 0.f};
         }
-        const int label = (int)labels[col];
-        const float labelp = probs[(size_t)label * numCases + col];
-        const float lp = logf(labelp);
-        const float cp = labelp != m ? 0.f : 1.0f / (float)cnt;
-        labelLogProbs[col] = lp;
-        correctProbs[col] = cp;
-        a0 += (double)lp;
-        a1 += (double)cp;
+#pragma unroll
+        for (int u = 0; u < SMF_MAXB; u++)
+            if (v[u][1] != 0.f) maxcnt_merge(m, cnt, v[u][0], (int)v[u][1]);
     }
-    sh0[threadIdx.x] = a0;
-    sh1[threadIdx.x] = a1;
+    shm[g][cl] = m;
+    shc[g][cl] = cnt;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { sh0[threadIdx.x] += sh0[threadIdx.x + o]; sh1[threadIdx.x] += sh1[threadIdx.x + o]; }
-        __syncthreads();
+    if (g == 0) {
+        double a0 = 0, a1 = 0;
+        if (live) {
+            for (int k = 1; k < 16; k++)
+                if (shc[k][cl] != 0) maxcnt_merge(m, cnt, shm[k][cl], shc[k][cl]);
+            const int label = (int)labels[col];
+            const float labelp = probs[(size_t)label * numCases + col];
+            const float lp = logf(labelp);
+            const float cp = labelp != m ? 0.f : 1.0f / (float)cnt;
+            labelLogProbs[col] = lp;
+            correctProbs[col] = cp;
+            a0 = (double)lp;
+            a1 = 1.0 - (double)cp;
+        }
+        sh0[cl] = a0;
+        sh1[cl] = a1;
     }
+    __syncthreads();
     if (threadIdx.x == 0 && costOut) {
-        costOut[0] += -sh0[0];
-        costOut[1] += (double)numCases - sh1[0];
+        double t0 = 0, t1 = 0;
+        for (int k = 0; k < SMF_COLS; k++) { t0 += sh0[k]; t1 += sh1[k]; }
+        atomicAdd(&costOut[0], -t0);
+        atomicAdd(&costOut[1], t1);
     }
 }
 MCN_API size_t mcn_logreg_cost_workspace_bytes(int numOut, int numCases) { return mcn_softmax_workspace_bytes(numOut, numCases); }
@@ -387,10 +458,11 @@ MCN_API int mcn_logreg_cost(const float* labels, const float* probs, float* labe
         mcn_set_error("logregCost: workspace %zu < %zu bytes", workspaceBytes, need);
         return MCN_EWORKSPACE;
     }
+    MCN_REQUIRE(chunks <= 65535, "logregCost: too many outputs");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_logreg_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, probs, (float*)workspace, numOut, numCases);
-    hipLaunchKernelGGL(k_logreg_final, dim3(1), dim3(256), 0, s, labels, probs, (const float*)workspace, labelLogProbs, correctProbs,
-                       numOut, numCases, chunks, costOut);
+    hipLaunchKernelGGL(k_logreg_final, dim3(divup(numCases, SMF_COLS)), dim3(256), 0, s, labels, probs, (const float*)workspace,
+                       labelLogProbs, correctProbs, numOut, numCases, chunks, costOut);
     return MCN_LAUNCH_CHECK("logregCost");
 }
 
@@ -445,21 +517,65 @@ MCN_API int mcn_softmax_grad(const float* acts, const float* actsGrad, float* ta
 // SquaredDiff + column-sum (layer_kernels.cu:554-561, kDumbAggCols) and of the CPU oracle, so the
 // data-dependent margin and every 1[d<m] decision agree bit for bit.  Phase 2: getOptimalThr
 // (:482-498) as an O(h) scan per candidate, first strict maximum wins.  Phase 3: cost or gradient.
-#define L2SN_MAX_PAIRS 4096
-__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs) {
+#define L2SN_MAX_PAIRS 2048
+#define L2SN_TILE 4096  // floats of squared differences staged per pass
+// Pair labels and distances.  The squares are computed by all threads into an LDS tile (independent,
+// coalesced loads); thread j then adds its column of the tile in row order -- the summation order of
+// the reference's SquaredDiff + column-sum and of the CPU oracle.
+__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs, float* sq) {
     const int h = numCases / 2;
+    const int TR = max(1, L2SN_TILE / h);
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
         labs[j] = idens[j] == idens[j + h] ? 1.f : -1.f;
-        float s = 0.f;
-        const float* g = data + j;
-        const float* q = data + j + h;
-#pragma unroll 8
-        for (int k = 0; k < numD; k++) {
-            const float d = g[(size_t)k * numCases] - q[(size_t)k * numCases];
-            s = __fadd_rn(s, __fmul_rn(d, d));
-        }
-        dists[j] = __fadd_rn(sqrtf(s), 0.00000001f);
+        dists[j] = 0.f;
     }
+    for (int k0 = 0; k0 < numD; k0 += TR) {
+        const int rows = min(TR, numD - k0);
+        for (int jb = 0; jb < h; jb += L2SN_TILE) {  // more than L2SN_TILE pairs: column blocks (TR == 1)
+            const int cols = min(h - jb, L2SN_TILE);
+            __syncthreads();
+            // batches of 8 independent load pairs per thread (a load-use chain per element would cost one
+            // L2 round trip each)
+            for (int e0 = threadIdx.x; e0 < rows * cols; e0 += 8 * blockDim.x) {
+                float gv[8], qv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * blockDim.x;
+                    if (e < rows * cols) {
+                        const int kk = e / cols, j = jb + e % cols;
+                        const float* g = data + (size_t)(k0 + kk) * numCases + j;
+                        gv[u] = g[0];
+                        qv[u] = g[h];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * blockDim.x;
+                    if (e < rows * cols) {
+                        const float d = gv[u] - qv[u];
+                        sq[e] = __fmul_rn(d, d);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int jj = threadIdx.x; jj < cols; jj += blockDim.x) {
+                float s = dists[jb + jj];
+                int kk = 0;
+                for (; kk + 8 <= rows; kk += 8) {
+                    float t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) t[u] = sq[(kk + u) * cols + jj];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) s = __fadd_rn(s, t[u]);
+                }
+                for (; kk < rows; kk++) s = __fadd_rn(s, sq[kk * cols + jj]);
+                dists[jb + jj] = s;
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < h; j += blockDim.x) dists[j] = __fadd_rn(sqrtf(dists[j]), 0.00000001f);
+    __syncthreads();
 }
 // returns (m, idx) in sh_m[0..1]; candidates/labels of length cnt
 __device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* rates, float* sh_m) {
@@ -470,19 +586,28 @@ __device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* r
         rates[i] = rate;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {  // first strict maximum: largest rate, lowest index among equals
         int best = 0, idx = 0;
-        for (int i = 0; i < cnt; i++)
+        for (int i = threadIdx.x; i < cnt; i += 64)
             if (rates[i] > best) { best = rates[i]; idx = i; }
-        sh_m[0] = cd[idx];
-        sh_m[1] = (float)idx;
+        if (best == 0) idx = 0;
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ob = __shfl_down(best, o, 64), oi = __shfl_down(idx, o, 64);
+            if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+        }
+        if (threadIdx.x == 0) {
+            sh_m[0] = cd[idx];
+            sh_m[1] = (float)idx;
+        }
     }
     __syncthreads();
 }
-template <int MODE>  // 0 cost, 1 grad, 2 stats only
+// MODE 0 cost (one block), 1 grad (block b owns rows [b*rowsPerBlock, ...): every block recomputes the
+// pair statistics and the margin -- 80 KB of L2 reads -- instead of a second launch), 2 stats only.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, const float* __restrict__ data, float* __restrict__ out,
                                               int numD, int numCases, float m, int add, float coeff, float* info, float* pairStats,
-                                              double* costOut, const float* extD, const float* extL, int extCount) {
+                                              double* costOut, const float* extD, const float* extL, int extCount, int rowsPerBlock) {
     extern __shared__ float shf[];
     const int h = numCases / 2;
     const int cnt = extD ? extCount : h;
@@ -491,14 +616,15 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
     float* cd = labs + h;            // [cnt] candidates when external
     float* cl = cd + (extD ? cnt : 0);
     int* rates = (int*)(cl + (extD ? cnt : 0));  // [cnt]
+    float* sq = (float*)(rates + cnt);           // [L2SN_TILE]
     __shared__ float sh_m[2];
     __shared__ double shsum[256];
-    l2sn_stats(idens, data, numD, numCases, dists, labs);
+    l2sn_stats(idens, data, numD, numCases, dists, labs, sq);
     if (extD) {
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) { cd[i] = extD[i]; cl[i] = extL[i]; }
     }
     __syncthreads();
-    if (pairStats) {
+    if (pairStats && blockIdx.x == 0) {
         for (int j = threadIdx.x; j < h; j += blockDim.x) { pairStats[j] = dists[j]; pairStats[h + j] = labs[j]; }
     }
     if (MODE == 2) return;
@@ -508,7 +634,7 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
         m = sh_m[0];
         idx = sh_m[1];
     }
-    if (info && threadIdx.x == 0) { info[0] = m; info[1] = idx; info[2] = 0.f; info[3] = 0.f; }
+    if (info && threadIdx.x == 0 && blockIdx.x == 0) { info[0] = m; info[1] = idx; info[2] = 0.f; info[3] = 0.f; }
     if (MODE == 0) {
         double a = 0;
         for (int j = threadIdx.x; j < h; j += blockDim.x) {
@@ -529,9 +655,10 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
         }
         if (threadIdx.x == 0 && costOut) *costOut += shsum[0];
     } else {
-        const size_t total = (size_t)numD * h;
-        for (size_t e = threadIdx.x; e < total; e += blockDim.x) {
-            const int k = (int)(e / h), j = (int)(e % h);
+        const int k0 = blockIdx.x * rowsPerBlock, k1 = min(numD, k0 + rowsPerBlock);
+        const int total = (k1 - k0) * h;
+        for (int e = threadIdx.x; e < total; e += blockDim.x) {
+            const int k = k0 + e / h, j = e % h;
             const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
             const float negMask2 = dists[j] < m ? 1.f : 0.f;
             const float r = __fadd_rn(__fmul_rn(1.0f / dists[j], m), -1.0f);
@@ -553,12 +680,14 @@ static int l2sn_launch(int mode, const float* idens, const float* data, float* o
     MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");  // layer_kernels.cu:511
     MCN_REQUIRE((extD == nullptr) == (extL == nullptr), "l2sn: extDists and extLabels go together");
     const int h = numCases / 2, cnt = extD ? extCount : h;
-    MCN_REQUIRE(h <= L2SN_MAX_PAIRS && cnt <= L2SN_MAX_PAIRS && cnt > 0, "l2sn: too many pairs (%d)", cnt);
-    const size_t lds = (size_t)(2 * h + (extD ? 2 * cnt : 0) + cnt) * 4;
+    MCN_REQUIRE(h <= L2SN_MAX_PAIRS && cnt <= L2SN_MAX_PAIRS && cnt > 0, "l2sn: too many pairs (%d, limit %d)", cnt, L2SN_MAX_PAIRS);
+    const size_t lds = (size_t)(2 * h + (extD ? 2 * cnt : 0) + cnt + L2SN_TILE) * 4;
     hipStream_t s = (hipStream_t)stream;
-#define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount
+    const int rowsPerBlock = std::max(1, 512 / h);  // two gradient elements per thread
+    const int gradBlocks = divup(numD, rowsPerBlock);
+#define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount, rowsPerBlock
     if (mode == 0) hipLaunchKernelGGL((k_l2sn<0>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
-    else if (mode == 1) hipLaunchKernelGGL((k_l2sn<1>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+    else if (mode == 1) hipLaunchKernelGGL((k_l2sn<1>), dim3(gradBlocks), dim3(256), lds, s, L2SN_ARGS);
     else hipLaunchKernelGGL((k_l2sn<2>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
 #undef L2SN_ARGS
     return MCN_LAUNCH_CHECK("l2sn");
@@ -649,4 +778,76 @@ MCN_API int mcn_sgd_update(float* W, float* inc, const float* grad, size_t n, fl
     else
         hipLaunchKernelGGL(k_sgd, dim3(ew_blocks(n)), dim3(256), 0, s, W, inc, grad, n, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
     return MCN_LAUNCH_CHECK("sgdUpdate");
+}
+
+// Weights::update for every matrix of the net in ONE launch.  The plan (one record per matrix, with the
+// first block index of each) lives in device memory and is built once; block b finds its record by a scan
+// over the few dozen records and updates SGD_BLOCK_ELEMS consecutive elements of that matrix.
+#define SGD_BLOCK_ELEMS 2048
+struct SgdRec {
+    float* W;
+    float* inc;
+    const float* grad;
+    unsigned long long n;
+    float mom, wcEps;
+    int useGrad, useWc;
+    unsigned blockStart, pad;
+};
+__global__ __launch_bounds__(256) void k_sgd_planned(const SgdRec* __restrict__ plan, int count) {
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int t = 0;
+        while (t + 1 < count && plan[t + 1].blockStart <= blockIdx.x) t++;
+        which = t;
+    }
+    __syncthreads();
+    const SgdRec r = plan[which];
+    const size_t base = (size_t)(blockIdx.x - r.blockStart) * SGD_BLOCK_ELEMS;
+#pragma unroll
+    for (int rep = 0; rep < SGD_BLOCK_ELEMS / 1024; rep++) {
+        const size_t i = base + (size_t)rep * 1024 + threadIdx.x * 4;
+        if (i + 3 < r.n) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(r.inc + i);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(r.W + i);
+            if (r.useGrad) v = r.mom * v + *reinterpret_cast<const f32x4*>(r.grad + i);
+            if (r.useWc) v = v + r.wcEps * w;
+            *reinterpret_cast<f32x4*>(r.inc + i) = v;
+            *reinterpret_cast<f32x4*>(r.W + i) = w + v;
+        } else {
+            for (size_t e = i; e < r.n && e < i + 4; e++) {
+                float v = r.inc[e];
+                const float w = r.W[e];
+                if (r.useGrad) v = r.mom * v + 1.f * r.grad[e];
+                if (r.useWc) v = 1.f * v + r.wcEps * w;
+                r.inc[e] = v;
+                r.W[e] = w + v;
+            }
+        }
+    }
+}
+MCN_API size_t mcn_sgd_plan_bytes(int count) { return (size_t)(count > 0 ? count : 1) * sizeof(SgdRec); }
+MCN_API int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, size_t planBytes, int* numBlocksOut, void* stream) {
+    MCN_REQUIRE(items && devicePlan && numBlocksOut && count > 0, "sgdPlanBuild: bad argument");
+    MCN_REQUIRE(planBytes >= mcn_sgd_plan_bytes(count), "sgdPlanBuild: plan buffer too small");
+    std::vector<SgdRec> recs(count);
+    unsigned blocks = 0;
+    for (int i = 0; i < count; i++) {
+        const mcn_sgd_item& it = items[i];
+        MCN_REQUIRE(it.W && it.inc && (!it.useGrad || it.grad) && it.n > 0, "sgdPlanBuild: item %d: null pointer or empty", i);
+        MCN_REQUIRE(al16(it.W) && al16(it.inc) && (!it.useGrad || al16(it.grad)), "sgdPlanBuild: item %d: buffers must be 16-byte aligned", i);
+        SgdRec& r = recs[i];
+        r.W = it.W; r.inc = it.inc; r.grad = it.grad; r.n = it.n;
+        r.mom = it.mom; r.wcEps = -it.wc * it.eps; r.useGrad = it.useGrad; r.useWc = it.wc > 0 ? 1 : 0;
+        r.blockStart = blocks; r.pad = 0;
+        blocks += (unsigned)divup_sz(it.n, SGD_BLOCK_ELEMS);
+    }
+    *numBlocksOut = (int)blocks;
+    int rc = mcn_check_hip(hipMemcpyAsync(devicePlan, recs.data(), recs.size() * sizeof(SgdRec), hipMemcpyHostToDevice, (hipStream_t)stream), "sgdPlanBuild upload");
+    if (rc) return rc;
+    return mcn_check_hip(hipStreamSynchronize((hipStream_t)stream), "sgdPlanBuild sync");  // recs goes out of scope
+}
+MCN_API int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream) {
+    MCN_REQUIRE(devicePlan && count > 0 && numBlocks > 0, "sgdUpdatePlanned: bad argument");
+    hipLaunchKernelGGL(k_sgd_planned, dim3(numBlocks), dim3(256), 0, (hipStream_t)stream, (const SgdRec*)devicePlan, count);
+    return MCN_LAUNCH_CHECK("sgdUpdatePlanned");
 }

@@ -101,6 +101,19 @@ void Weights::update(bool dp, void* stream) {
     }
 }
 
+bool Weights::planItem(bool dp, ::mcn_sgd_item& it) {
+    if (_src || !(_eps > 0)) return false;
+    it.W = _W.p;
+    it.inc = _inc.p;
+    it.useGrad = (_useGrad || dp) ? 1 : 0;
+    it.grad = it.useGrad ? _grad : nullptr;
+    it.n = size();
+    it.mom = _mom;
+    it.wc = _wc;
+    it.eps = _eps;
+    return true;
+}
+
 void Weights::hostImage(std::vector<float>& out, void* stream) {
     std::vector<float> tmp(size());
     chk(mcn_d2h(tmp.data(), W(), size() * 4, stream), "d2h");
@@ -274,6 +287,10 @@ void WeightLayer::updateWeights() {
     ProfScope ps(_net, _name, "update");
     for (auto& w : _weights) w->update(_net->dataParallel(), _net->stream());
     _biases->update(_net->dataParallel(), _net->stream());
+}
+void WeightLayer::weightsUpdated() {
+    for (auto& w : _weights) w->updated();
+    _biases->updated();
 }
 void WeightLayer::copyToCPU() {
     for (auto& w : _weights) w->copyToCPU(_net->stream());
@@ -858,6 +875,22 @@ void ConvNet::allocate(int maxCases) {
     _gradArena.ensure(std::max<size_t>(total, 4));
     chk(mcn_memset(_gradArena.p, 0, _gradArena.cap * 4, _stream), "memset grads");
     for (auto& pw : place) pw.first->setGradBuf(_gradArena.p + pw.second);
+    // one-launch update plan over every matrix that is updated
+    std::vector<::mcn_sgd_item> items;
+    for (auto& l : _layers) {
+        std::vector<Weights*> ws_;
+        l->collectWeights(ws_);
+        for (Weights* w : ws_) {
+            ::mcn_sgd_item it;
+            if (w->planItem(dp, it)) items.push_back(it);
+        }
+    }
+    _sgdCount = (int)items.size();
+    if (_sgdCount > 0) {
+        const size_t pb = mcn_sgd_plan_bytes(_sgdCount);
+        _sgdPlan.ensure((pb + 3) / 4);
+        chk(mcn_sgd_plan_build(items.data(), _sgdCount, _sgdPlan.p, pb, &_sgdBlocks, _stream), "sgd plan");
+    }
     int nc = 0;
     for (CostLayer* c : _costs) nc += c->numCostValues();
     _costBuf.ensure(std::max(2 * nc, 4));
@@ -919,7 +952,13 @@ void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
 
 void ConvNet::updateWeights() {  // convnet.cu:190-194
     if (dataParallel()) waitComm();
-    for (auto& l : _layers) l->updateWeights();
+    if (_sgdCount > 0 && _fusion) {
+        ProfScope ps(this, "net", "update");
+        chk(mcn_sgd_update_planned(_sgdPlan.p, _sgdCount, _sgdBlocks, _stream), "sgd update");
+        for (auto& l : _layers) l->weightsUpdated();
+    } else {
+        for (auto& l : _layers) l->updateWeights();
+    }
 }
 
 void ConvNet::copyToCPU() {

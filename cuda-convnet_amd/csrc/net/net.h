@@ -25,6 +25,8 @@
 
 #include "params.h"
 
+struct mcn_sgd_item;  // include/mi_convnet.h
+
 namespace mcn {
 
 enum PassType { PASS_TRAIN = 0, PASS_TEST = 1, PASS_GC = 2 };  // util.cuh:43
@@ -73,6 +75,8 @@ class Weights {
     void copyToGPU(void* stream);
     void copyToCPU(void* stream);
     void update(bool dp, void* stream);  // weights.cuh:150-163, one fused kernel
+    bool planItem(bool dp, ::mcn_sgd_item& it);  // record for the all-matrices update; false: nothing to update
+    void updated() { if (!_src) _numUpdates = 0; }
     // host <-> device image conversion for gradient checking
     void hostImage(std::vector<float>& out, void* stream);        // logical (rows, cols) row-major
     void setElement(long r, long c, float v, void* stream);
@@ -111,6 +115,7 @@ class Layer {
     virtual void allocate(int maxCases);  // device buffers for up to maxCases columns
     virtual size_t workspaceBytes(int maxCases) { return 0; }
     virtual void updateWeights() {}
+    virtual void weightsUpdated() {}
     virtual void copyToCPU() {}
     virtual void copyToGPU() {}
     virtual void checkGradients(std::vector<struct GradCheckResult>& out, long maxElems, bool central) {}
@@ -167,6 +172,7 @@ class WeightLayer : public Layer {
    public:
     WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortran);
     void updateWeights() override;
+    void weightsUpdated() override;
     void copyToCPU() override;
     void copyToGPU() override;
     void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) override;
@@ -486,6 +492,8 @@ class ConvNet {
     DBuf _ws;
     DBuf _gradArena;
     DBuf _costBuf;  // doubles, viewed as floats x2
+    DBuf _sgdPlan;  // device records of the one-launch weight update
+    int _sgdCount = 0, _sgdBlocks = 0;
     std::vector<double> _costHost;
     double _baseErr = 0;
 

@@ -258,6 +258,21 @@ int mcn_l2reg_grad(const float* ground, const float* data, float* target, int nu
 int mcn_sgd_update(float* W, float* inc, const float* grad, size_t n, float mom, float wc, float eps,
                    int useGrad, void* stream);
 
+/* The same update for every matrix of a net in ONE launch (the reference launches up to three
+ * kEltwiseBinaryOp per matrix, weights.cuh:150-163).  Build the plan once (uploads `count` records to
+ * devicePlan, blocking), then launch it every step.  All buffers must be 16-byte aligned. */
+typedef struct mcn_sgd_item {
+    float* W;
+    float* inc;
+    const float* grad; /* read only when useGrad != 0 */
+    size_t n;
+    float mom, wc, eps;
+    int useGrad;
+} mcn_sgd_item;
+size_t mcn_sgd_plan_bytes(int count);
+int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, size_t planBytes, int* numBlocksOut, void* stream);
+int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream);
+
 /* ---- data-parallel exchange (no counterpart in the reference, which is single-GPU: convnet.py:52-53).
  * RCCL is loaded lazily; one communicator per process (one process per GPU). */
 int mcn_comm_unique_id(char idBytes[128]);

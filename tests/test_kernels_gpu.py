@@ -661,3 +661,31 @@ def test_sgd_update(n, use_grad, wc):
     call('mcn_sgd_update', d_W, d_inc, dev(grad), n, 0.9, wc, 5e-4, use_grad, None)
     close(d_inc.numpy(), wInc, rtol=1e-6, atol=1e-12, what='inc')
     close(d_W.numpy(), wW, rtol=1e-6, what='W')
+
+
+def test_sgd_update_planned_matches_per_matrix_update():
+    """Every matrix in one launch (mcn_sgd_update_planned) == the oracle's per-matrix Weights::update."""
+    class Item(C.Structure):
+        _fields_ = [('W', C.c_void_p), ('inc', C.c_void_p), ('grad', C.c_void_p), ('n', C.c_size_t),
+                    ('mom', C.c_float), ('wc', C.c_float), ('eps', C.c_float), ('useGrad', C.c_int)]
+    rng = np.random.default_rng(11)
+    specs = [(768, 1, 5e-4), (28800 * 48, 0, 5e-4), (1001, 1, 0.0), (3, 1, 0.0), (2049, 0, 0.0), (4096, 1, 5e-4)]
+    host, devs, items = [], [], (Item * len(specs))()
+    for i, (n, ug, wc) in enumerate(specs):
+        W, inc, g = mk(rng, n), mk(rng, n, scale=0.01), mk(rng, n, scale=0.001)
+        dW, dI, dG = dev(W), dev(inc), dev(g)
+        devs.append((dW, dI, dG))
+        host.append((W, inc, g))
+        items[i] = Item(dW.ptr, dI.ptr, dG.ptr if ug else None, n, 0.9, wc, 5e-4, ug)
+    L = capi.lib()
+    plan = capi.workspace(ws_bytes('mcn_sgd_plan_bytes', len(specs)))
+    nb = C.c_int(0)
+    L.call('mcn_sgd_plan_build', C.cast(items, C.c_void_p), len(specs), plan, plan.nbytes, C.byref(nb), None)
+    assert nb.value == sum((n + 2047) // 2048 for n, _, _ in specs)
+    for _ in range(2):  # two consecutive steps
+        L.call('mcn_sgd_update_planned', plan, len(specs), nb.value, None)
+        for (W, inc, g), (n, ug, wc) in zip(host, specs):
+            O.sgd_update(W, inc, g, 0.9, wc, 5e-4, ug)
+    for (W, inc, g), (dW, dI, dG), spec in zip(host, devs, specs):
+        close(dW.numpy(), W, rtol=1e-6, what='W %r' % (spec,))
+        close(dI.numpy(), inc, rtol=1e-6, what='inc %r' % (spec,))
