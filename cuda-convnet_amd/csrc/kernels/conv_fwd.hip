@@ -5,7 +5,8 @@
 // and the in-place neuron of layer.cu:249.
 //
 // Implicit GEMM per module m:  out[f, n] = sum_k W[(m,) k, f] * patch_m[k, n],
-// k = (c, fy, fx).  One wave owns (one module) x (16*FV filters) x (64*NQ images).
+// k = (c, fy, fx).  One wave owns (one module) x (16*FV filters) x (64*NQ images); for layers with few
+// modules (local layers) the four waves of a block split K of one such tile and are summed through LDS.
 // v_mfma_f32_16x16x4_f32 operands come straight from the reference layouts:
 //   A[row=f][k]  : lane (i=l&15, kk=l>>4) reads FV consecutive filters of weight row k0+kk
 //   B[k][col=n]  : lane (j=l&15, kk=l>>4) reads 4 consecutive images of patch row k0+kk
@@ -13,6 +14,7 @@
 // freely, component u of the A vector / t of the B vector feed MFMA (u,t): 16-byte
 // loads along the contiguous dimensions and 16-byte stores, no LDS transposes.
 // The k -> (channel,fy,fx) decode is tabulated once per workgroup in LDS.
+#include <algorithm>
 #include "common.h"
 
 struct FwdParams {
@@ -28,13 +30,17 @@ struct FwdParams {
 template <int FV>
 struct AVec { float v[FV]; };
 
-template <int FV, int NQ, bool VECN>
-__global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
+// k-steps (of 4) loaded per batch: all loads of a batch are issued before its MFMAs and the next batch is
+// prefetched into a second register set while the current one is multiplied (the shapes here have at most a
+// few waves per SIMD, so load latency has to be hidden inside the wave)
+template <int FV, int NQ, int U, bool KSPLIT, bool VECN>
+__global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
     extern __shared__ int tbl[];
+    constexpr int KB = 4 * U, T = FV * NQ * 4;
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
-    const int K = fc * fp, K4 = (K + 3) & ~3, M = p.mY * p.mX;
+    const int K = fc * fp, Kpad = (K + KB - 1) / KB * KB, M = p.mY * p.mX;
     const int imgPixels = p.imgY * p.imgX;
-    for (int k = threadIdx.x; k < K4; k += 256) {
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
         if (k < K) {
             const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
             tbl[2 * k] = c * imgPixels + fy * p.imgX + fx;
@@ -46,8 +52,10 @@ __global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int m = blockIdx.y * 4 + wave;
-    if (m >= M) return;
+    // KSPLIT: the four waves of the block share one module and take its k-batches round-robin (summed
+    // through LDS below); otherwise each wave owns its own module.
+    const int m = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
+    if (!KSPLIT && m >= M) return;
     const int n0 = blockIdx.x * (64 * NQ);
     const int f0 = blockIdx.z * (16 * FV);
     const int grp = f0 / fpg;
@@ -56,6 +64,7 @@ __global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
 
     const float* ib = p.images + ((ptrdiff_t)grp * fc * imgPixels + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride + n0 + 4 * j;
     const float* wb = p.filters + (size_t)(p.conv ? 0 : m) * K * p.F + f0 + FV * j;
+    const float* safe = p.images;  // always-valid address for lanes whose element is outside the image / batch
 
     f32x4 acc[FV][NQ * 4];
 #pragma unroll
@@ -63,32 +72,94 @@ __global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
 #pragma unroll
         for (int t = 0; t < NQ * 4; t++) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // biases first: their latency hides behind the whole k-loop instead of stalling the epilogue
+    float biasv[FV][4];
+#pragma unroll
+    for (int u = 0; u < FV; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = f0 + FV * (4 * kk + r) + u;
+            biasv[u][r] = p.biases ? p.biases[p.biasPerModule ? (size_t)f * M + m : f] : 0.f;
+        }
 
-    for (int k0 = 0; k0 < K; k0 += 4) {
-        const int k = k0 + kk;
-        const int off = tbl[2 * k], yx = tbl[2 * k + 1];
-        const int kc = k < K ? k : K - 1;
-        const AVec<FV> a = *reinterpret_cast<const AVec<FV>*>(wb + (size_t)kc * p.F);
-        bool inb = k < K;
-        if (check) inb = inb && (unsigned)(y0 + (yx >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx & 0xffff)) < (unsigned)p.imgX;
-        const float* src = ib + (ptrdiff_t)off * p.imgStride;
-        f32x4 b[NQ];
+    AVec<FV> a0[U], a1[U];
+    f32x4 b0[U][NQ], b1[U][NQ];
+    auto load = [&](int kbase, AVec<FV>(&a)[U], f32x4(&b)[U][NQ]) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const int n = n0 + 64 * q + 4 * j;
-            if (VECN) {
-                b[q] = (inb && n < p.N) ? *reinterpret_cast<const f32x4*>(src + 64 * q) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            } else {
+        for (int s = 0; s < U; s++) {
+            const int k = kbase + 4 * s + kk;
+            const int off = tbl[2 * k], yx = tbl[2 * k + 1];
+            const int kc = k < K ? k : K - 1;
+            a[s] = *reinterpret_cast<const AVec<FV>*>(wb + (size_t)kc * p.F);
+            bool inb = true;
+            if (check) inb = (unsigned)(y0 + (yx >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx & 0xffff)) < (unsigned)p.imgX;
+            const float* src = ib + (ptrdiff_t)off * p.imgStride;
 #pragma unroll
-                for (int t = 0; t < 4; t++) b[q][t] = (inb && n + t < p.N) ? src[64 * q + t] : 0.f;
+            for (int q = 0; q < NQ; q++) {
+                const int n = n0 + 64 * q + 4 * j;
+                if (VECN) {
+                    const bool ok = inb && n < p.N;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? src + 64 * q : safe);
+                    b[s][q] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const bool ok = inb && n + t < p.N;
+                        const float v = *(ok ? src + 64 * q + t : safe);
+                        b[s][q][t] = ok ? v : 0.f;
+                    }
+                }
             }
         }
+    };
+    auto compute = [&](const AVec<FV>(&a)[U], const f32x4(&b)[U][NQ]) {
+#pragma unroll
+        for (int s = 0; s < U; s++)
+#pragma unroll
+            for (int u = 0; u < FV; u++)
+#pragma unroll
+                for (int q = 0; q < NQ; q++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[u][q * 4 + t] = mfma16(a[s].v[u], b[s][q][t], acc[u][q * 4 + t]);
+    };
+    const int kFirst = KSPLIT ? wave * KB : 0, kStep = KSPLIT ? 4 * KB : KB;
+    if (kFirst < K) load(kFirst, a0, b0);
+    for (int kb = kFirst; kb < K; kb += 2 * kStep) {
+        const bool more1 = kb + kStep < K, more2 = kb + 2 * kStep < K;
+        if (more1) load(kb + kStep, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(kb + 2 * kStep, a0, b0);
+            compute(a1, b1);
+        }
+    }
+
+    bool mine[FV * NQ];  // which (filter vector, image quad) groups this wave stores
+#pragma unroll
+    for (int g = 0; g < FV * NQ; g++) mine[g] = true;
+    if (KSPLIT) {
+        // fixed-order sum of the four waves' accumulators; group g = u*NQ + q is finished and stored by wave g % 4
+        __syncthreads();
+        f32x4* red = reinterpret_cast<f32x4*>(tbl);
 #pragma unroll
         for (int u = 0; u < FV; u++)
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
+            for (int t = 0; t < NQ * 4; t++) red[(wave * T + u * NQ * 4 + t) * 64 + lane] = acc[u][t];
+        __syncthreads();
 #pragma unroll
-                for (int t = 0; t < 4; t++) acc[u][q * 4 + t] = mfma16(a.v[u], b[q][t], acc[u][q * 4 + t]);
+        for (int u = 0; u < FV; u++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                mine[u * NQ + q] = ((u * NQ + q) & 3) == wave;
+                if (mine[u * NQ + q]) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int tile = u * NQ * 4 + q * 4 + t;
+                        acc[u][q * 4 + t] = (red[(0 * T + tile) * 64 + lane] + red[(1 * T + tile) * 64 + lane]) +
+                                            (red[(2 * T + tile) * 64 + lane] + red[(3 * T + tile) * 64 + lane]);
+                    }
+                }
+            }
     }
 
     // D row (4*kk + r) of MFMA u  <->  filter f0 + FV*(4*kk + r) + u ; col j, MFMA t <-> image n0+64q+4j+t
@@ -97,11 +168,11 @@ __global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int f = f0 + FV * (4 * kk + r) + u;
-            float bias = 0.f;
-            if (p.biases) bias = p.biases[p.biasPerModule ? (size_t)f * M + m : f];
+            const float bias = biasv[u][r];
             float* trow = p.targets + ((size_t)f * M + m) * p.N;
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
+                if (!mine[u * NQ + q]) continue;
                 const int n = n0 + 64 * q + 4 * j;
                 f32x4 v;
 #pragma unroll
@@ -126,16 +197,41 @@ __global__ __launch_bounds__(256) void k_filter_acts(FwdParams p) {
     }
 }
 
+template <int FV, int NQ, int U>
+static void launch_fwd3(const FwdParams& p, dim3 grid, size_t lds, bool vecn, bool ksplit, hipStream_t s) {
+    if (ksplit) {
+        if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, false>), grid, dim3(256), lds, s, p);
+    } else {
+        if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, false, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, false, false>), grid, dim3(256), lds, s, p);
+    }
+}
+
+// k-steps per batch: 12 when the tile is small enough to hold two such register sets and K divides (conv1's
+// K = 48 then needs a single round trip), else 8, or 4 for the widest tiles
+static int fwd_batch(int FV, int NQ, int K) {
+    if (FV * NQ >= 4) return 4;
+    if (FV * NQ <= 2 && K % 48 == 0 && K % 32 != 0) return 12;
+    return 8;
+}
+
 template <int FV, int NQ>
-static void launch_fwd2(const FwdParams& p, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
-    if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_filter_acts<FV, NQ, false>), grid, dim3(256), lds, s, p);
+static void launch_fwd2(const FwdParams& p, int U, dim3 grid, size_t lds, bool vecn, bool ksplit, hipStream_t s) {
+    if constexpr (FV * NQ >= 4) {
+        launch_fwd3<FV, NQ, 4>(p, grid, lds, vecn, ksplit, s);
+    } else if constexpr (FV * NQ <= 2) {
+        if (U == 12) launch_fwd3<FV, NQ, 12>(p, grid, lds, vecn, ksplit, s);
+        else launch_fwd3<FV, NQ, 8>(p, grid, lds, vecn, ksplit, s);
+    } else {
+        launch_fwd3<FV, NQ, 8>(p, grid, lds, vecn, ksplit, s);
+    }
 }
 
 template <int FV>
-static void launch_fwd1(const FwdParams& p, int nq, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
-    if (nq == 2) launch_fwd2<FV, 2>(p, grid, lds, vecn, s);
-    else launch_fwd2<FV, 1>(p, grid, lds, vecn, s);
+static void launch_fwd1(const FwdParams& p, int nq, int U, dim3 grid, size_t lds, bool vecn, bool ksplit, hipStream_t s) {
+    if (nq == 2) launch_fwd2<FV, 2>(p, U, grid, lds, vecn, ksplit, s);
+    else launch_fwd2<FV, 1>(p, U, grid, lds, vecn, ksplit, s);
 }
 
 static int filter_acts_impl(const float* images, const float* filters, const float* biases, float* targets,
@@ -167,28 +263,40 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
     p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY) || (K % 4 != 0);
 
     const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)targets) % 16 == 0);
-    // tile choice: largest filter vector that divides the group's filter tiles, then shrink until
-    // the launch has at least one wave per SIMD (1024 on MI355X)
     const int ftiles = fpg / 16;
-    int FV = ftiles % 4 == 0 ? 4 : ftiles % 3 == 0 ? 3 : ftiles % 2 == 0 ? 2 : 1;
-    int NQ = N > 64 ? 2 : 1;
+    auto best_fv = [&](int cap) {
+        for (int fv = cap; fv > 1; fv--)
+            if (ftiles % fv == 0) return fv;
+        return 1;
+    };
+    int FV = best_fv(4), NQ = N > 64 ? 2 : 1;
+    bool ksplit = false;
     auto waves = [&](int fv, int nq) { return (long)divup(N, 64 * nq) * M * (F / (16 * fv)); };
-    if (waves(FV, NQ) < 1024 && NQ == 2) NQ = 1;
-    while (waves(FV, NQ) < 1024 && FV > 1) {
-        int nf = FV - 1;
-        while (nf > 1 && ftiles % nf != 0) nf--;
-        FV = nf;
+    if (waves(1, 1) * 4 <= 4096 && K >= 128) {
+        // few modules (the unshared local layers): one block per (module, filter vector, 64 images), its four
+        // waves split K.  Wide filter vectors keep the weight rows read in long contiguous pieces.
+        ksplit = true;
+        NQ = 1;
+        FV = best_fv(3);
+    } else {
+        // tile choice: largest filter vector that divides the group's filter tiles, then shrink until
+        // the launch has at least one wave per SIMD (1024 on MI355X)
+        if (waves(FV, NQ) < 1024 && NQ == 2) NQ = 1;
+        while (waves(FV, NQ) < 1024 && FV > 1) FV = best_fv(FV - 1);
     }
-    dim3 grid(divup(N, 64 * NQ), divup(M, 4), F / (16 * FV));
+    const int U = fwd_batch(FV, NQ, K), KB = 4 * U;
+    if (K % KB != 0) p.check = 1;  // the padded k of the last batch must load zeros
+    dim3 grid(divup(N, 64 * NQ), ksplit ? M : divup(M, 4), F / (16 * FV));
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "filterActs: grid too large");
-    const size_t lds = (size_t)((K + 3) & ~3) * 8;
+    size_t lds = (size_t)divup(K, KB) * KB * 8;
+    if (ksplit) lds = std::max(lds, (size_t)4 * FV * NQ * 4 * 64 * 16);
     MCN_REQUIRE(lds <= 64 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
     hipStream_t s = (hipStream_t)stream;
     switch (FV) {
-        case 4: launch_fwd1<4>(p, NQ, grid, lds, vecn, s); break;
-        case 3: launch_fwd1<3>(p, NQ, grid, lds, vecn, s); break;
-        case 2: launch_fwd1<2>(p, NQ, grid, lds, vecn, s); break;
-        default: launch_fwd1<1>(p, NQ, grid, lds, vecn, s); break;
+        case 4: launch_fwd1<4>(p, NQ, U, grid, lds, vecn, ksplit, s); break;
+        case 3: launch_fwd1<3>(p, NQ, U, grid, lds, vecn, ksplit, s); break;
+        case 2: launch_fwd1<2>(p, NQ, U, grid, lds, vecn, ksplit, s); break;
+        default: launch_fwd1<1>(p, NQ, U, grid, lds, vecn, ksplit, s); break;
     }
     return MCN_LAUNCH_CHECK("filterActs");
 }

@@ -9,10 +9,11 @@
 // Every operand is read with 16-byte loads along its contiguous dimension; the
 // free index (TN: m, all: n) or the reduction index (NN: A, NT: both) of
 // v_mfma_f32_16x16x4_f32 is permuted accordingly (same trick as the conv kernels),
-// so no operand goes through LDS.  M here is 160..10575 with n = 128 cases, so
-// occupancy, not tile size, is the lever: the host picks tiles / split-K so that
-// the launch has >= 1 wave per SIMD; split-K partials are reduced in a fixed
-// order by a second kernel (deterministic, no atomics).
+// so no operand goes through LDS.  M here is 160..10575 with n = 128 cases: the
+// launches are small, so latency is hidden inside the wave (batched loads with a
+// prefetched second register set) and K is split over the waves of a workgroup
+// (summed through LDS); an inter-block split with a fixed-order second pass is
+// used only for very long K (fc6 backward-data).  Deterministic, no atomics.
 #include <algorithm>
 #include "common.h"
 
@@ -22,7 +23,7 @@ struct GemmParams {
     float* C;        // final output
     float* part;     // split-K partials [splits][M][N] (or null)
     const float* bias;
-    int M, N, K, kChunk, splits, vec, neuron;
+    int M, N, K, kChunk, splits, vec, avec, cvec, neuron;
     float alpha, beta, na, nb;
 };
 
@@ -36,6 +37,30 @@ __device__ __forceinline__ void gemm_store(const GemmParams& p, int m, int n, fl
     *c = o;
 }
 
+// four consecutive columns n..n+3 of row m
+__device__ __forceinline__ void gemm_store4(const GemmParams& p, int m, int n, f32x4 v) {
+    if (p.cvec && n + 3 < p.N) {
+        float* base = p.part ? p.part + ((size_t)blockIdx.z * p.M + m) * p.N + n : p.C + (size_t)m * p.N + n;
+        if (!p.part) {
+            v = p.alpha * v;
+            if (p.beta != 0.f) v += p.beta * *reinterpret_cast<const f32x4*>(base);
+            if (p.bias) v += p.bias[m];
+            if (p.neuron != MCN_NEURON_IDENT) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = neuron_apply(p.neuron, v[t], p.na, p.nb);
+            }
+        }
+        *reinterpret_cast<f32x4*>(base) = v;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if (n + t >= p.N) continue;
+            if (p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n + t] = v[t];
+            else gemm_store(p, m, n + t, v[t]);
+        }
+    }
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* ptr, bool vec, int idx, int limit) {
     // 4 consecutive floats starting at logical index idx of a row with `limit` valid entries
     if (vec) return idx < limit ? *reinterpret_cast<const f32x4*>(ptr) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -45,205 +70,323 @@ __device__ __forceinline__ f32x4 ld4(const float* ptr, bool vec, int idx, int li
     return r;
 }
 
-// ---- NN: A[MxK] row-major, B[KxN] row-major.  wave: 16*MV rows x 64*NQ cols.
-template <int MV, int NQ>
-__global__ __launch_bounds__(256) void k_gemm_nn(GemmParams p) {
+// ---------------------------------------------------------------------------------------------
+// All three kernels share one structure.  A workgroup of NW waves owns ONE C tile; its waves take the
+// k-batches of the block's K range round-robin, each batch being U k-steps whose loads are all issued
+// before its MFMAs while the next batch is prefetched into a second register set (M, N and the wave
+// counts here are small: load latency has to be hidden inside the wave, not by occupancy).  The waves'
+// accumulators are summed through LDS in a fixed halving tree and wave 0 finishes the tile
+// (alpha/beta/bias/neuron, or the split-K partial).
+// ---------------------------------------------------------------------------------------------
+// halving tree over the waves of the block (fixed order); afterwards wave 0 holds the sums
+template <int T>
+__device__ __forceinline__ void gemm_wave_tree_sum(f32x4 (&acc)[T], f32x4* red, int wave, int lane, int NW) {
+    for (int h = NW >> 1; h >= 1; h >>= 1) {
+        __syncthreads();
+        if (wave >= h && wave < 2 * h) {
+#pragma unroll
+            for (int t = 0; t < T; t++) red[((wave - h) * T + t) * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+        if (wave < h) {
+#pragma unroll
+            for (int t = 0; t < T; t++) acc[t] += red[(wave * T + t) * 64 + lane];
+        }
+    }
+    // publish the totals so that every wave can finish a share of the tile (a single wave issuing the whole
+    // epilogue would dominate the kernel: one wave retires roughly one vector instruction per 4-8 cycles)
+    if (NW > 1) {
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < T; t++) red[t * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- NN: A[MxK] row-major, B[KxN] row-major.  block tile: 16*MV rows x 64*NQ cols, k-step = 16.
+template <int MV, int NQ, int U>
+__global__ __launch_bounds__(512) void k_gemm_nn(const GemmParams p) {
+    extern __shared__ f32x4 red[];
+    constexpr int T = MV * NQ * 4;
+    const int NW = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int mt = blockIdx.y * 4 + wave;
-    const int m0 = mt * 16 * MV;
-    if (m0 >= p.M) return;
-    const int n0 = blockIdx.x * 64 * NQ;
+    const int m0 = blockIdx.y * 16 * MV, n0 = blockIdx.x * 64 * NQ;
     const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     const bool vec = p.vec != 0;
-    f32x4 acc[MV][NQ * 4];
+    f32x4 acc[T];
 #pragma unroll
-    for (int v = 0; v < MV; v++)
-#pragma unroll
-        for (int t = 0; t < NQ * 4; t++) acc[v][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* arow[MV];
 #pragma unroll
     for (int v = 0; v < MV; v++) arow[v] = p.A + (size_t)min(m0 + 16 * v + j, p.M - 1) * p.K + 4 * kk;
-    for (int k16 = kBeg; k16 < kEnd; k16 += 16) {
-        const int ka = k16 + 4 * kk;
-        f32x4 a[MV];
+    const float* bcol = p.B + n0 + 4 * j;
+
+    f32x4 a0[U][MV], a1[U][MV], b0[U][4][NQ], b1[U][4][NQ];
+    auto load = [&](int kb, f32x4(&a)[U][MV], f32x4(&b)[U][4][NQ]) {
 #pragma unroll
-        for (int v = 0; v < MV; v++) a[v] = ld4(arow[v] + k16, vec, ka, kEnd);
-        f32x4 b[4][NQ];
+        for (int s = 0; s < U; s++) {
+            const int k16 = kb + 16 * s, ka = k16 + 4 * kk;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int kr = ka + s;
-            const float* br = p.B + (size_t)min(kr, p.K - 1) * p.N + n0 + 4 * j;
+            for (int v = 0; v < MV; v++) a[s][v] = ld4(arow[v] + k16, vec, ka, kEnd);
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                b[s][q] = ld4(br + 64 * q, vec, n0 + 64 * q + 4 * j, kr < kEnd ? p.N : 0);
+            for (int e = 0; e < 4; e++) {
+                const int kr = ka + e;
+                const float* br = bcol + (size_t)min(kr, p.K - 1) * p.N;
+#pragma unroll
+                for (int q = 0; q < NQ; q++) b[s][e][q] = ld4(br + 64 * q, vec, n0 + 64 * q + 4 * j, kr < kEnd ? p.N : 0);
             }
         }
+    };
+    auto compute = [&](const f32x4(&a)[U][MV], const f32x4(&b)[U][4][NQ]) {
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < U; s++)
 #pragma unroll
-            for (int v = 0; v < MV; v++)
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int v = 0; v < MV; v++)
+#pragma unroll
+                    for (int q = 0; q < NQ; q++)
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+                            acc[(v * NQ + q) * 4 + t] = mfma16(a[s][v][e], b[s][e][q][t], acc[(v * NQ + q) * 4 + t]);
+    };
+    const int KB = 16 * U, kStep = KB * NW;
+    const int kFirst = kBeg + wave * KB;
+    if (kFirst < kEnd) load(kFirst, a0, b0);
+    for (int kb = kFirst; kb < kEnd; kb += 2 * kStep) {
+        const bool more1 = kb + kStep < kEnd, more2 = kb + 2 * kStep < kEnd;
+        if (more1) load(kb + kStep, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(kb + 2 * kStep, a0, b0);
+            compute(a1, b1);
+        }
+    }
+    gemm_wave_tree_sum<T>(acc, red, wave, lane, NW);
+#pragma unroll
+    for (int v = 0; v < MV; v++)
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            if ((v * NQ + q) % NW != wave) continue;
+            f32x4 sum[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) sum[t] = NW > 1 ? red[((v * NQ + q) * 4 + t) * 64 + lane] : acc[(v * NQ + q) * 4 + t];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 16 * v + 4 * kk + r;
+                if (m >= p.M) continue;
+                gemm_store4(p, m, n0 + 64 * q + 4 * j, (f32x4){sum[0][r], sum[1][r], sum[2][r], sum[3][r]});
+            }
+        }
+}
+
+// ---- TN: A stored [KxM] (m contiguous), B[KxN].  block tile: 64 rows x 64*NQ cols, k-step = 4.
+// Lane (j, kk) reads 4 consecutive m of row k0+kk; component u of that vector feeds MFMA tile u, whose row j
+// is therefore m0 + 4j + u (the M index of an MFMA may be permuted freely).
+template <int NQ, int U>
+__global__ __launch_bounds__(512) void k_gemm_tn(const GemmParams p) {
+    extern __shared__ f32x4 red[];
+    constexpr int T = 4 * NQ * 4;
+    const int NW = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64 * NQ;
+    const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
+    const bool vec = p.vec != 0, avec = p.avec != 0;
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* ab = p.A + m0 + 4 * j;
+    const float* bb = p.B + n0 + 4 * j;
+
+    f32x4 a0[U], a1[U], b0[U][NQ], b1[U][NQ];
+    auto load = [&](int kb, f32x4(&a)[U], f32x4(&b)[U][NQ]) {
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+            const int k = kb + 4 * s + kk;
+            const bool kin = k < kEnd;
+            const size_t kr = (size_t)min(k, p.K - 1);
+            a[s] = ld4(ab + kr * p.M, avec, m0 + 4 * j, kin ? p.M : 0);
+#pragma unroll
+            for (int q = 0; q < NQ; q++) b[s][q] = ld4(bb + kr * p.N + 64 * q, vec, n0 + 64 * q + 4 * j, kin ? p.N : 0);
+        }
+    };
+    auto compute = [&](const f32x4(&a)[U], const f32x4(&b)[U][NQ]) {
+#pragma unroll
+        for (int s = 0; s < U; s++)
+#pragma unroll
+            for (int u = 0; u < 4; u++)
 #pragma unroll
                 for (int q = 0; q < NQ; q++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) acc[v][q * 4 + t] = mfma16(a[v][s], b[s][q][t], acc[v][q * 4 + t]);
+                    for (int t = 0; t < 4; t++) acc[(u * NQ + q) * 4 + t] = mfma16(a[s][u], b[s][q][t], acc[(u * NQ + q) * 4 + t]);
+    };
+    const int KB = 4 * U, kStep = KB * NW;
+    const int kFirst = kBeg + wave * KB;
+    if (kFirst < kEnd) load(kFirst, a0, b0);
+    for (int kb = kFirst; kb < kEnd; kb += 2 * kStep) {
+        const bool more1 = kb + kStep < kEnd, more2 = kb + 2 * kStep < kEnd;
+        if (more1) load(kb + kStep, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(kb + 2 * kStep, a0, b0);
+            compute(a1, b1);
+        }
     }
+    gemm_wave_tree_sum<T>(acc, red, wave, lane, NW);
 #pragma unroll
-    for (int v = 0; v < MV; v++)
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = m0 + 16 * v + 4 * kk + r;
-            if (m >= p.M) continue;
+        for (int q = 0; q < NQ; q++) {
+            if ((u * NQ + q) % NW != wave) continue;
+            f32x4 sum[4];
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
+            for (int t = 0; t < 4; t++) sum[t] = NW > 1 ? red[((u * NQ + q) * 4 + t) * 64 + lane] : acc[(u * NQ + q) * 4 + t];
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int n = n0 + 64 * q + 4 * j + t;
-                    if (n >= p.N) continue;
-                    if (p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[v][q * 4 + t][r];
-                    else gemm_store(p, m, n, acc[v][q * 4 + t][r]);
-                }
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 4 * (4 * kk + r) + u;
+                if (m >= p.M) continue;
+                gemm_store4(p, m, n0 + 64 * q + 4 * j, (f32x4){sum[0][r], sum[1][r], sum[2][r], sum[3][r]});
+            }
         }
 }
 
-// ---- TN: A stored [KxM] (m contiguous), B[KxN].  wave: 16*MV rows (vector of MV per lane) x 64*NQ cols.
-template <int MV, int NQ>
-__global__ __launch_bounds__(256) void k_gemm_tn(GemmParams p) {
+// ---- NT: A[MxK], B stored [NxK] (both k contiguous).  block tile: 16*MV rows x 16*NV cols, k-step = 16.
+template <int MV, int NV, int U>
+__global__ __launch_bounds__(512) void k_gemm_nt(const GemmParams p) {
+    extern __shared__ f32x4 red[];
+    constexpr int T = MV * NV;
+    const int NW = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int mt = blockIdx.y * 4 + wave;
-    const int m0 = mt * 16 * MV;
-    if (m0 >= p.M) return;
-    const int n0 = blockIdx.x * 64 * NQ;
+    const int m0 = blockIdx.y * 16 * MV, n0 = blockIdx.x * 16 * NV;
     const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     const bool vec = p.vec != 0;
-    f32x4 acc[MV][NQ * 4];
+    f32x4 acc[T];
 #pragma unroll
-    for (int v = 0; v < MV; v++)
-#pragma unroll
-        for (int t = 0; t < NQ * 4; t++) acc[v][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kBeg; k0 < kEnd; k0 += 4) {
-        const int k = k0 + kk;
-        const bool kin = k < kEnd;
-        const float* ar = p.A + (size_t)min(k, p.K - 1) * p.M + m0 + MV * j;
-        float a[MV];
-#pragma unroll
-        for (int u = 0; u < MV; u++) a[u] = (kin && m0 + MV * j + u < p.M) ? ar[u] : 0.f;
-        const float* br = p.B + (size_t)min(k, p.K - 1) * p.N + n0 + 4 * j;
-        f32x4 b[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; q++) b[q] = ld4(br + 64 * q, vec, n0 + 64 * q + 4 * j, kin ? p.N : 0);
-#pragma unroll
-        for (int u = 0; u < MV; u++)
-#pragma unroll
-            for (int q = 0; q < NQ; q++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) acc[u][q * 4 + t] = mfma16(a[u], b[q][t], acc[u][q * 4 + t]);
-    }
-#pragma unroll
-    for (int u = 0; u < MV; u++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = m0 + MV * (4 * kk + r) + u;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int q = 0; q < NQ; q++)
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int n = n0 + 64 * q + 4 * j + t;
-                    if (n >= p.N) continue;
-                    if (p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[u][q * 4 + t][r];
-                    else gemm_store(p, m, n, acc[u][q * 4 + t][r]);
-                }
-        }
-}
-
-// ---- NT: A[MxK], B stored [NxK] (both k contiguous).  wave: 16*MV rows x 16*NV cols.
-template <int MV, int NV>
-__global__ __launch_bounds__(256) void k_gemm_nt(GemmParams p) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int mt = blockIdx.y * 4 + wave;
-    const int m0 = mt * 16 * MV;
-    if (m0 >= p.M) return;
-    const int n0 = blockIdx.x * 16 * NV;
-    const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
-    const bool vec = p.vec != 0;
-    f32x4 acc[MV][NV];
-#pragma unroll
-    for (int v = 0; v < MV; v++)
-#pragma unroll
-        for (int u = 0; u < NV; u++) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* arow[MV];
     const float* brow[NV];
 #pragma unroll
     for (int v = 0; v < MV; v++) arow[v] = p.A + (size_t)min(m0 + 16 * v + j, p.M - 1) * p.K + 4 * kk;
 #pragma unroll
     for (int u = 0; u < NV; u++) brow[u] = p.B + (size_t)min(n0 + 16 * u + j, p.N - 1) * p.K + 4 * kk;
-    for (int k16 = kBeg; k16 < kEnd; k16 += 16) {
-        const int ka = k16 + 4 * kk;
-        f32x4 a[MV], b[NV];
+
+    f32x4 a0[U][MV], a1[U][MV], b0[U][NV], b1[U][NV];
+    auto load = [&](int kb, f32x4(&a)[U][MV], f32x4(&b)[U][NV]) {
 #pragma unroll
-        for (int v = 0; v < MV; v++) a[v] = ld4(arow[v] + k16, vec, ka, kEnd);
+        for (int s = 0; s < U; s++) {
+            const int k16 = kb + 16 * s, ka = k16 + 4 * kk;
 #pragma unroll
-        for (int u = 0; u < NV; u++) b[u] = ld4(brow[u] + k16, vec, ka, kEnd);
+            for (int v = 0; v < MV; v++) a[s][v] = ld4(arow[v] + k16, vec, ka, kEnd);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
+            for (int u = 0; u < NV; u++) b[s][u] = ld4(brow[u] + k16, vec, ka, kEnd);
+        }
+    };
+    auto compute = [&](const f32x4(&a)[U][MV], const f32x4(&b)[U][NV]) {
 #pragma unroll
-            for (int v = 0; v < MV; v++)
+        for (int s = 0; s < U; s++)
 #pragma unroll
-                for (int u = 0; u < NV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int v = 0; v < MV; v++)
+#pragma unroll
+                    for (int u = 0; u < NV; u++) acc[v * NV + u] = mfma16(a[s][v][e], b[s][u][e], acc[v * NV + u]);
+    };
+    const int KB = 16 * U, kStep = KB * NW;
+    const int kFirst = kBeg + wave * KB;
+    if (kFirst < kEnd) load(kFirst, a0, b0);
+    for (int kb = kFirst; kb < kEnd; kb += 2 * kStep) {
+        const bool more1 = kb + kStep < kEnd, more2 = kb + 2 * kStep < kEnd;
+        if (more1) load(kb + kStep, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(kb + 2 * kStep, a0, b0);
+            compute(a1, b1);
+        }
     }
+    gemm_wave_tree_sum<T>(acc, red, wave, lane, NW);
 #pragma unroll
     for (int v = 0; v < MV; v++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int m = m0 + 16 * v + 4 * kk + r;
-            if (m >= p.M) continue;
+        for (int u = 0; u < NV; u++) {
+            if ((v * NV + u) % NW != wave) continue;
+            const f32x4 sum = NW > 1 ? red[(v * NV + u) * 64 + lane] : acc[v * NV + u];
+            const int n = n0 + 16 * u + j;
+            if (n >= p.N) continue;
 #pragma unroll
-            for (int u = 0; u < NV; u++) {
-                const int n = n0 + 16 * u + j;
-                if (n >= p.N) continue;
-                if (p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = acc[v][u][r];
-                else gemm_store(p, m, n, acc[v][u][r]);
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + 16 * v + 4 * kk + r;
+                if (m >= p.M) continue;
+                if (p.part) p.part[((size_t)blockIdx.z * p.M + m) * p.N + n] = sum[r];
+                else gemm_store(p, m, n, sum[r]);
             }
         }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_reduce(GemmParams p) {
+// split-K partials [splits][M*N] -> C, 4 elements per thread, slabs added in index order
+__global__ __launch_bounds__(256) void k_gemm_reduce(const GemmParams p) {
     const size_t total = (size_t)p.M * p.N;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int z = 0; z < p.splits; z++) s += p.part[(size_t)z * total + i];
-        gemm_store(p, (int)(i / p.N), (int)(i % p.N), s);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    if (i + 3 < total && total % 4 == 0) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(p.part + i);
+        int z = 1;
+        for (; z + 3 < p.splits; z += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p.part + (size_t)z * total + i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p.part + (size_t)(z + 1) * total + i);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p.part + (size_t)(z + 2) * total + i);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p.part + (size_t)(z + 3) * total + i);
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; z < p.splits; z++) s += *reinterpret_cast<const f32x4*>(p.part + (size_t)z * total + i);
+#pragma unroll
+        for (int t = 0; t < 4; t++) gemm_store(p, (int)((i + t) / p.N), (int)((i + t) % p.N), s[t]);
+    } else {
+        for (size_t e = i; e < total && e < i + 4; e++) {
+            float s = 0.f;
+            for (int z = 0; z < p.splits; z++) s += p.part[(size_t)z * total + e];
+            gemm_store(p, (int)(e / p.N), (int)(e % p.N), s);
+        }
     }
 }
 
-struct GemmPlan { int mv, nv, splits, kChunk; };
+// Tile / wave-count / split choice.  ksteps: k-steps of the variant (16 k for NN/NT, 4 k for TN).
+struct GemmPlan { int mv, nv, u, nw, splits, kChunk; };
 
 static GemmPlan gemm_plan(int M, int N, int K, int ta, int tb) {
     GemmPlan pl;
-    const long target = 1024;
-    if (!tb) {
-        // NN / TN: cols in quads of 64
-        int nq = N > 64 ? 2 : 1;
-        int mv = ta ? 4 : 2;
-        auto waves = [&](int mv_, int nq_) { return (long)divup(M, 16 * mv_) * divup(N, 64 * nq_); };
-        if (waves(mv, nq) < target && nq == 2) nq = 1;
-        while (waves(mv, nq) < target && mv > 1) mv /= 2;
-        pl.mv = mv; pl.nv = nq;
-        const long w = waves(mv, nq);
-        int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(w, 1)), std::max(1, K / 64));
-        pl.kChunk = divup(divup(K, splits), 16) * 16;
-        pl.splits = divup(K, pl.kChunk);
-    } else {
-        int mv = 3, nv = 2;
-        auto waves = [&](int mv_, int nv_) { return (long)divup(M, 16 * mv_) * divup(N, 16 * nv_); };
-        while (waves(mv, nv) < target && mv > 1) mv--;
-        if (waves(mv, nv) < target && nv == 2) nv = 1;
-        pl.mv = mv; pl.nv = nv;
-        const long w = waves(mv, nv);
-        int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(w, 1)), std::max(1, K / 64));
-        pl.kChunk = divup(divup(K, splits), 16) * 16;
-        pl.splits = divup(K, pl.kChunk);
+    const int kstep = ta ? 4 : 16;
+    long tiles;
+    if (tb) {          // NT: 16*mv x 16*nv
+        const int ntl = divup(N, 16);
+        pl.mv = 1;
+        pl.nv = ntl % 5 == 0 ? 5 : ntl % 4 == 0 ? 4 : ntl % 3 == 0 ? 3 : ntl % 2 == 0 ? 2 : (ntl >= 8 ? 4 : 1);
+        tiles = (long)divup(M, 16 * pl.mv) * divup(N, 16 * pl.nv);
+        pl.u = 2;
+    } else if (ta) {   // TN: 64 x 64*nv
+        pl.mv = 4;
+        pl.nv = 1;
+        tiles = (long)divup(M, 64) * divup(N, 64);
+        pl.u = 4;
+    } else {           // NN: 16*mv x 64*nv
+        pl.mv = 1;
+        pl.nv = (N > 64 && (long)divup(M, 16) * divup(N, 128) >= 512) ? 2 : 1;
+        tiles = (long)divup(M, 16) * divup(N, 64 * pl.nv);
+        pl.u = 2;
     }
+    const int ksteps = divup(K, kstep);
+    const int batches = divup(ksteps, pl.u);
+    // waves per block: as many as there are k-batches, up to 16 (fewer when the grid is already large)
+    int nw = tiles >= 1024 ? 4 : 8;  // at most 8 waves (512 threads): keeps 256 VGPRs per lane for the two register sets
+    while (nw > 1 && nw > batches) nw /= 2;
+    pl.nw = nw;
+    // inter-block split only when a wave would still walk many batches and the grid is small
+    int splits = 1;
+    const int perWave = divup(batches, nw);
+    if (perWave > 4 && tiles * nw < 2048) splits = (int)std::min<long>(std::min<long>(divup(perWave, 3), 2048 / (tiles * nw) + 1), 64);
+    pl.kChunk = divup(divup(K, splits), kstep * pl.u) * kstep * pl.u;
+    pl.splits = divup(K, pl.kChunk);
     return pl;
 }
 
@@ -273,45 +416,43 @@ static int gemm_impl(const float* A, const float* B, const float* bias, float* C
         }
         p.part = (float*)workspace;
     }
-    // 16-byte loads need: NN: K%4 (A rows) and N%4 (B rows); TN: N%4; NT: K%4
+    // 16-byte loads need: NN: K%4 (A rows) and N%4 (B rows); TN: M%4 (A rows) and N%4; NT: K%4
     const bool a16 = ((uintptr_t)A % 16) == 0, b16 = ((uintptr_t)B % 16) == 0;
+    p.avec = 0;
+    p.cvec = N % 4 == 0 && ((uintptr_t)C % 16) == 0 && (!p.part || ((uintptr_t)p.part % 16) == 0);
     if (!ta && !tb) p.vec = a16 && b16 && K % 4 == 0 && N % 4 == 0;
-    else if (ta) p.vec = b16 && N % 4 == 0;
+    else if (ta) { p.vec = b16 && N % 4 == 0; p.avec = a16 && M % 4 == 0; }
     else p.vec = a16 && b16 && K % 4 == 0;
     hipStream_t s = (hipStream_t)stream;
-    if (!tb) {
-        dim3 grid(divup(N, 64 * pl.nv), divup(divup(M, 16 * pl.mv), 4), pl.splits);
+    const dim3 block(64 * pl.nw);
+    if (!ta && !tb) {
+        dim3 grid(divup(N, 64 * pl.nv), divup(M, 16 * pl.mv), pl.splits);
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
-#define LAUNCH(KERN, MVv, NQv) hipLaunchKernelGGL((KERN<MVv, NQv>), grid, dim3(256), 0, s, p)
-        if (!ta) {
-            if (pl.mv == 2 && pl.nv == 2) LAUNCH(k_gemm_nn, 2, 2);
-            else if (pl.mv == 2) LAUNCH(k_gemm_nn, 2, 1);
-            else if (pl.nv == 2) LAUNCH(k_gemm_nn, 1, 2);
-            else LAUNCH(k_gemm_nn, 1, 1);
-        } else {
-            if (pl.mv == 4 && pl.nv == 2) LAUNCH(k_gemm_tn, 4, 2);
-            else if (pl.mv == 4) LAUNCH(k_gemm_tn, 4, 1);
-            else if (pl.mv == 2 && pl.nv == 2) LAUNCH(k_gemm_tn, 2, 2);
-            else if (pl.mv == 2) LAUNCH(k_gemm_tn, 2, 1);
-            else if (pl.nv == 2) LAUNCH(k_gemm_tn, 1, 2);
-            else LAUNCH(k_gemm_tn, 1, 1);
-        }
+        const size_t lds = (size_t)std::max(1, pl.nw / 2) * pl.mv * pl.nv * 4 * 64 * 16;
+        if (pl.nv == 2) hipLaunchKernelGGL((k_gemm_nn<1, 2, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((k_gemm_nn<1, 1, 2>), grid, block, lds, s, p);
+    } else if (ta) {
+        dim3 grid(divup(N, 64), divup(M, 64), pl.splits);
+        MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+        const size_t lds = (size_t)std::max(1, pl.nw / 2) * 16 * 64 * 16;
+        hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, block, lds, s, p);
     } else {
-        dim3 grid(divup(N, 16 * pl.nv), divup(divup(M, 16 * pl.mv), 4), pl.splits);
+        dim3 grid(divup(N, 16 * pl.nv), divup(M, 16 * pl.mv), pl.splits);
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
-        if (pl.mv == 3 && pl.nv == 2) LAUNCH(k_gemm_nt, 3, 2);
-        else if (pl.mv == 3) LAUNCH(k_gemm_nt, 3, 1);
-        else if (pl.mv == 2 && pl.nv == 2) LAUNCH(k_gemm_nt, 2, 2);
-        else if (pl.mv == 2) LAUNCH(k_gemm_nt, 2, 1);
-        else if (pl.nv == 2) LAUNCH(k_gemm_nt, 1, 2);
-        else LAUNCH(k_gemm_nt, 1, 1);
-#undef LAUNCH
+        const size_t lds = (size_t)std::max(1, pl.nw / 2) * pl.mv * pl.nv * 64 * 16;
+        switch (pl.nv) {
+            case 5: hipLaunchKernelGGL((k_gemm_nt<1, 5, 2>), grid, block, lds, s, p); break;
+            case 4: hipLaunchKernelGGL((k_gemm_nt<1, 4, 2>), grid, block, lds, s, p); break;
+            case 3: hipLaunchKernelGGL((k_gemm_nt<1, 3, 2>), grid, block, lds, s, p); break;
+            case 2: hipLaunchKernelGGL((k_gemm_nt<1, 2, 2>), grid, block, lds, s, p); break;
+            default: hipLaunchKernelGGL((k_gemm_nt<1, 1, 2>), grid, block, lds, s, p); break;
+        }
     }
     int rc = MCN_LAUNCH_CHECK("gemm");
     if (rc) return rc;
     if (pl.splits > 1) {
         const size_t total = (size_t)M * N;
-        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)std::min<size_t>(divup_sz(total, 256), 4096)), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)divup_sz(total, 1024)), dim3(256), 0, s, p);
         rc = MCN_LAUNCH_CHECK("gemm reduce");
     }
     return rc;

@@ -269,6 +269,7 @@ float WeightLayer::gradScale(float eps, PassType pt) const {
 }
 
 void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
+    _net->beginGradWork();
     if (_biases->eps() > 0) {
         ProfScope ps(_net, _name, "bpropBiases");
         bpropBiases(v, pt);
@@ -281,6 +282,7 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
         }
     }
     if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
+    _net->endGradWork();
 }
 
 void WeightLayer::updateWeights() {
@@ -578,6 +580,7 @@ void ResponseNormLayer::fpropActs(int, float, PassType) {
 }
 
 void ResponseNormLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // destroys own acts like the reference
+    _net->joinGradWork();  // a weight-gradient kernel of the layer above may still be reading those acts
     const int n = _net->numCases();
     if (_cross)
         chk(mcn_response_norm_cross_map_undo(v, _denoms.p, _prev[0]->getActs(), _acts, _prev[0]->getActsGrad(), n, _channels,
@@ -604,8 +607,11 @@ size_t LogregCostLayer::workspaceBytes(int maxCases) { return mcn_logreg_cost_wo
 
 void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
     if (i != 0) return;
+    // the cost value is off the critical path (nothing downstream reads it): side stream
+    _net->beginGradWork();
     chk(mcn_logreg_cost(_inputs[0], _inputs[1], _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
                         _net->workspaceBytes(), _net->stream()), "logreg cost");
+    _net->endGradWork();
 }
 
 void LogregCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:983-994
@@ -651,8 +657,11 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         _net->allGather(_pairStats.p + h, _gathered.p + (size_t)h * G, h);
         _extCount = h * G;
     }
+    const bool side = !_net->dataParallel();  // data-parallel: stays in stream order with the all-gather above
+    if (side) _net->beginGradWork();
     chk(mcn_l2sn_cost(_inputs[0], _inputs[1], _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
                       _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+    if (side) _net->endGradWork();
 }
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
@@ -665,7 +674,9 @@ void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  //
 
 void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
     if (i != 0) return;
+    _net->beginGradWork();
     chk(mcn_l2reg_cost(_inputs[0], _inputs[1], _acts, _prev[1]->outputs(), _net->numCases(), dCost, _net->stream()), "l2reg cost");
+    _net->endGradWork();
 }
 
 void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1107-1116
@@ -773,6 +784,9 @@ ConvNet::~ConvNet() {
     if (_commStream) mcn_stream_destroy(_commStream);
     if (_evGrad) mcn_event_destroy(_evGrad);
     if (_evComm) mcn_event_destroy(_evComm);
+    if (_gradStream) mcn_stream_destroy(_gradStream);
+    if (_evFork) mcn_event_destroy(_evFork);
+    if (_evJoin) mcn_event_destroy(_evJoin);
     if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
 }
@@ -843,6 +857,12 @@ void ConvNet::run() {  // convnet.cu:147-156
 void ConvNet::initDevice() {  // convnet.cu:139-145
     chk(mcn_set_device(_deviceID < 0 ? 0 : _deviceID), "set device");
     chk(mcn_stream_create(&_stream), "stream");
+    _cur = _stream;
+    if (getenv("MCN_NO_GRAD_STREAM") == nullptr) {
+        chk(mcn_stream_create(&_gradStream), "grad stream");
+        chk(mcn_event_create(&_evFork), "event");
+        chk(mcn_event_create(&_evJoin), "event");
+    }
     for (auto& l : _layers) l->copyToGPU();
     buildFusions();
     allocate(_minibatchSize);
@@ -853,6 +873,7 @@ void ConvNet::allocate(int maxCases) {
     size_t ws = 256;
     for (auto& l : _layers) ws = std::max(ws, l->workspaceBytes(maxCases));
     _ws.ensure((ws + 3) / 4);
+    if (_gradStream) _ws2.ensure((ws + 3) / 4);
     // gradient arena in reverse layer order == the order in which backward completes them, so that
     // data-parallel buckets are contiguous ranges
     const bool dp = dataParallel();
@@ -922,9 +943,30 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     }
 }
 
-void ConvNet::sync() { chk(mcn_stream_sync(_stream), "sync"); }
+void ConvNet::sync() {
+    joinGradWork();
+    chk(mcn_stream_sync(_stream), "sync");
+}
+
+void ConvNet::beginGradWork() {
+    if (!_gradStream || _profiling) return;  // profiling times every operation on the main stream
+    chk(mcn_event_record(_evFork, _stream), "event record");
+    chk(mcn_stream_wait_event(_gradStream, _evFork), "wait event");
+    _cur = _gradStream;
+    _gradPending = true;
+}
+
+void ConvNet::endGradWork() { _cur = _stream; }
+
+void ConvNet::joinGradWork() {
+    if (!_gradPending) return;
+    chk(mcn_event_record(_evJoin, _gradStream), "event record");
+    chk(mcn_stream_wait_event(_stream, _evJoin), "wait event");
+    _gradPending = false;
+}
 
 void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
+    joinGradWork();  // side-stream work of the previous minibatch (cost values in a test pass) reads buffers rewritten below
     for (auto& l : _layers) l->reset();
     for (DataLayer* d : _dataLayers) {
         if (d->dataIdx < 0 || d->dataIdx >= (int)_curData.size()) throw NetError("data layer '" + d->name() + "': no data matrix " + std::to_string(d->dataIdx));
@@ -936,6 +978,7 @@ void ConvNet::fpropSlice(long start, long end, PassType pt) {
     end = std::min(end, _dp->numCases());
     _numCases = (int)(end - start);
     if (_numCases > _allocatedCases) throw NetError("minibatch larger than the allocated size");
+    joinGradWork();  // the slice buffers (labels) may still be read by cost kernels of the previous minibatch
     _dp->getSlice(start, end, _curData);
     fpropCurrent(pt);
 }
@@ -948,6 +991,7 @@ void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
     for (CostLayer* c : _costs) c->bprop(pt);
     for (auto& l : _layers) l->reset();
     if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
+    joinGradWork();
 }
 
 void ConvNet::updateWeights() {  // convnet.cu:190-194
@@ -983,7 +1027,7 @@ void ConvNet::flushBuckets(bool force) {
     }
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
-    chk(mcn_event_record(_evGrad, _stream), "event record");
+    chk(mcn_event_record(_evGrad, _gradPending ? _gradStream : _stream), "event record");
     chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
     chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
     _sentUpTo = end;
@@ -1061,9 +1105,13 @@ void ConvNet::profCollect(std::map<std::string, ProfEntry>& into) {
 }
 
 // ---- costs --------------------------------------------------------------------------------------
-void ConvNet::zeroCosts() { chk(mcn_memset(_costBuf.p, 0, _costBuf.cap * 4, _stream), "zero costs"); }
+void ConvNet::zeroCosts() {
+    joinGradWork();  // cost kernels accumulate on the side stream
+    chk(mcn_memset(_costBuf.p, 0, _costBuf.cap * 4, _stream), "zero costs");
+}
 
 void ConvNet::readCosts(Cost& into, long numCases) {
+    joinGradWork();
     if (!_costHost.empty()) chk(mcn_d2h(_costHost.data(), _costBuf.p, _costHost.size() * 8, _stream), "d2h costs");
     sync();
     int k = 0;

@@ -454,12 +454,18 @@ class ConvNet {
     void runSteps(int numSteps, bool test, bool profile);
 
     // ---- services for layers ---------------------------------------------------------------
-    void* stream() const { return _stream; }
+    void* stream() const { return _cur; }       // the stream layer operations are issued on right now
+    void* mainStream() const { return _stream; }
+    // Weight / bias gradients of a layer depend only on its incoming gradient, so they run on a side stream
+    // next to the backward-data chain (joined before the update, before anything overwrites their inputs).
+    void beginGradWork();
+    void endGradWork();
+    void joinGradWork();
     int numCases() const { return _numCases; }
     int worldSize() const { return _world; }
     int rank() const { return _rank; }
     bool dataParallel() const { return _dpOn; }
-    void* workspace() const { return _ws.p; }
+    void* workspace() const { return _cur == _gradStream && _gradStream ? _ws2.p : _ws.p; }
     size_t workspaceBytes() const { return _ws.cap * sizeof(float); }
     Layer& layer(int i) { return *_layers[i]; }
     int numLayers() const { return (int)_layers.size(); }
@@ -489,7 +495,12 @@ class ConvNet {
     std::vector<float*> _curData;
 
     void* _stream = nullptr;
-    DBuf _ws;
+    void* _cur = nullptr;
+    void* _gradStream = nullptr;  // null: gradients stay on the main stream
+    void* _evFork = nullptr;
+    void* _evJoin = nullptr;
+    bool _gradPending = false;
+    DBuf _ws, _ws2;
     DBuf _gradArena;
     DBuf _costBuf;  // doubles, viewed as floats x2
     DBuf _sgdPlan;  // device records of the one-launch weight update
