@@ -529,48 +529,59 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
         labs[j] = idens[j] == idens[j + h] ? 1.f : -1.f;
         dists[j] = 0.f;
     }
+    // 16-byte loads need h % 4 == 0 (the probe half then starts on a 16-byte boundary too)
+    const bool vec = (h % 4 == 0) && (((uintptr_t)data) % 16 == 0);
+    const int hq = h / 4;                       // quads per half row
+    const int rq = threadIdx.x / max(hq, 1), jq = threadIdx.x % max(hq, 1);  // vector path: (row lane, quad)
+    const int RV = max(1, (int)blockDim.x / max(hq, 1));                    // rows per pass
     for (int k0 = 0; k0 < numD; k0 += TR) {
         const int rows = min(TR, numD - k0);
-        for (int jb = 0; jb < h; jb += L2SN_TILE) {  // more than L2SN_TILE pairs: column blocks (TR == 1)
-            const int cols = min(h - jb, L2SN_TILE);
-            __syncthreads();
-            // batches of 8 independent load pairs per thread (a load-use chain per element would cost one
-            // L2 round trip each)
-            for (int e0 = threadIdx.x; e0 < rows * cols; e0 += 8 * blockDim.x) {
-                float gv[8], qv[8];
+        __syncthreads();
+        if (vec && hq <= (int)blockDim.x) {
+            // batches of 4 independent row loads per thread
+            for (int kb = rq; kb < rows && rq < RV; kb += 4 * RV) {
+                f32x4 gv[4], qv[4];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int e = e0 + u * blockDim.x;
-                    if (e < rows * cols) {
-                        const int kk = e / cols, j = jb + e % cols;
-                        const float* g = data + (size_t)(k0 + kk) * numCases + j;
-                        gv[u] = g[0];
-                        qv[u] = g[h];
+                for (int u = 0; u < 4; u++) {
+                    const int kk = kb + u * RV;
+                    if (kk < rows) {
+                        const float* g = data + (size_t)(k0 + kk) * numCases + 4 * jq;
+                        gv[u] = *reinterpret_cast<const f32x4*>(g);
+                        qv[u] = *reinterpret_cast<const f32x4*>(g + h);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int e = e0 + u * blockDim.x;
-                    if (e < rows * cols) {
-                        const float d = gv[u] - qv[u];
-                        sq[e] = __fmul_rn(d, d);
+                for (int u = 0; u < 4; u++) {
+                    const int kk = kb + u * RV;
+                    if (kk < rows) {
+                        f32x4 d = gv[u] - qv[u];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) d[t] = __fmul_rn(d[t], d[t]);
+                        *reinterpret_cast<f32x4*>(sq + kk * h + 4 * jq) = d;
                     }
                 }
             }
-            __syncthreads();
-            for (int jj = threadIdx.x; jj < cols; jj += blockDim.x) {
-                float s = dists[jb + jj];
-                int kk = 0;
-                for (; kk + 8 <= rows; kk += 8) {
-                    float t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) t[u] = sq[(kk + u) * cols + jj];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) s = __fadd_rn(s, t[u]);
-                }
-                for (; kk < rows; kk++) s = __fadd_rn(s, sq[kk * cols + jj]);
-                dists[jb + jj] = s;
+        } else {
+            for (int e = threadIdx.x; e < rows * h; e += blockDim.x) {
+                const int kk = e / h, j = e % h;
+                const float* g = data + (size_t)(k0 + kk) * numCases + j;
+                const float d = g[0] - g[h];
+                sq[e] = __fmul_rn(d, d);
             }
+        }
+        __syncthreads();
+        for (int jj = threadIdx.x; jj < h; jj += blockDim.x) {
+            float s = dists[jj];
+            int kk = 0;
+            for (; kk + 8 <= rows; kk += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = sq[(kk + u) * h + jj];
+#pragma unroll
+                for (int u = 0; u < 8; u++) s = __fadd_rn(s, t[u]);
+            }
+            for (; kk < rows; kk++) s = __fadd_rn(s, sq[kk * h + jj]);
+            dists[jj] = s;
         }
     }
     __syncthreads();
@@ -656,9 +667,10 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
         if (threadIdx.x == 0 && costOut) *costOut += shsum[0];
     } else {
         const int k0 = blockIdx.x * rowsPerBlock, k1 = min(numD, k0 + rowsPerBlock);
-        const int total = (k1 - k0) * h;
-        for (int e = threadIdx.x; e < total; e += blockDim.x) {
-            const int k = k0 + e / h, j = e % h;
+        const int rowStep = max(1, (int)blockDim.x / h);
+        const int j0 = threadIdx.x % h, r0 = threadIdx.x / h;  // one division per thread, none per element
+        for (int k = k0 + r0; k < k1 && r0 < rowStep; k += rowStep)
+        for (int j = j0; j < h; j += blockDim.x) {
             const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
             const float negMask2 = dists[j] < m ? 1.f : 0.f;
             const float r = __fadd_rn(__fmul_rn(1.0f / dists[j], m), -1.0f);

@@ -60,6 +60,12 @@ MCN_API int mcn_event_create(void** event) {
     *event = (void*)e;
     return rc;
 }
+MCN_API int mcn_event_create_sync(void** event) {  // ordering only: no timestamps
+    hipEvent_t e;
+    int rc = mcn_check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreateWithFlags");
+    *event = (void*)e;
+    return rc;
+}
 MCN_API int mcn_event_destroy(void* event) { return mcn_check_hip(hipEventDestroy((hipEvent_t)event), "hipEventDestroy"); }
 MCN_API int mcn_event_record(void* event, void* stream) {
     return mcn_check_hip(hipEventRecord((hipEvent_t)event, (hipStream_t)stream), "hipEventRecord");

@@ -269,20 +269,20 @@ float WeightLayer::gradScale(float eps, PassType pt) const {
 }
 
 void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
-    _net->beginGradWork();
-    if (_biases->eps() > 0) {
-        ProfScope ps(_net, _name, "bpropBiases");
-        bpropBiases(v, pt);
-    }
-    for (int i = 0; i < (int)_weights.size(); i++) {
-        if (_weights[i]->eps() > 0) {
-            ProfScope ps(_net, _name, "bpropWeights", i);
-            bpropWeights(v, i, pt);
-            _weights[i]->incNumUpdates();
+    _net->deferSideWork([this, v, pt] {
+        if (_biases->eps() > 0) {
+            ProfScope ps(_net, _name, "bpropBiases");
+            bpropBiases(v, pt);
         }
-    }
-    if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
-    _net->endGradWork();
+        for (int i = 0; i < (int)_weights.size(); i++) {
+            if (_weights[i]->eps() > 0) {
+                ProfScope ps(_net, _name, "bpropWeights", i);
+                bpropWeights(v, i, pt);
+                _weights[i]->incNumUpdates();
+            }
+        }
+        if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
+    }, 1);
 }
 
 void WeightLayer::updateWeights() {
@@ -580,7 +580,7 @@ void ResponseNormLayer::fpropActs(int, float, PassType) {
 }
 
 void ResponseNormLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // destroys own acts like the reference
-    _net->joinGradWork();  // a weight-gradient kernel of the layer above may still be reading those acts
+    _net->joinGradWork();  // a (deferred) weight-gradient kernel of the layer above still has to read those acts
     const int n = _net->numCases();
     if (_cross)
         chk(mcn_response_norm_cross_map_undo(v, _denoms.p, _prev[0]->getActs(), _acts, _prev[0]->getActsGrad(), n, _channels,
@@ -608,10 +608,11 @@ size_t LogregCostLayer::workspaceBytes(int maxCases) { return mcn_logreg_cost_wo
 void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
     if (i != 0) return;
     // the cost value is off the critical path (nothing downstream reads it): side stream
-    _net->beginGradWork();
-    chk(mcn_logreg_cost(_inputs[0], _inputs[1], _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
-                        _net->workspaceBytes(), _net->stream()), "logreg cost");
-    _net->endGradWork();
+    float *labels = _inputs[0], *probs = _inputs[1];
+    _net->deferSideWork([this, labels, probs] {
+        chk(mcn_logreg_cost(labels, probs, _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
+                            _net->workspaceBytes(), _net->stream()), "logreg cost");
+    }, 0);
 }
 
 void LogregCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:983-994
@@ -657,11 +658,11 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         _net->allGather(_pairStats.p + h, _gathered.p + (size_t)h * G, h);
         _extCount = h * G;
     }
-    const bool side = !_net->dataParallel();  // data-parallel: stays in stream order with the all-gather above
-    if (side) _net->beginGradWork();
-    chk(mcn_l2sn_cost(_inputs[0], _inputs[1], _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
-                      _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
-    if (side) _net->endGradWork();
+    float *idens = _inputs[0], *data = _inputs[1];
+    _net->deferSideWork([this, idens, data, D, n] {
+        chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
+                          _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+    }, 0);
 }
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
@@ -674,9 +675,10 @@ void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  //
 
 void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
     if (i != 0) return;
-    _net->beginGradWork();
-    chk(mcn_l2reg_cost(_inputs[0], _inputs[1], _acts, _prev[1]->outputs(), _net->numCases(), dCost, _net->stream()), "l2reg cost");
-    _net->endGradWork();
+    float *ground = _inputs[0], *pred = _inputs[1];
+    _net->deferSideWork([this, ground, pred] {
+        chk(mcn_l2reg_cost(ground, pred, _acts, _prev[1]->outputs(), _net->numCases(), dCost, _net->stream()), "l2reg cost");
+    }, 0);
 }
 
 void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1107-1116
@@ -860,8 +862,8 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
     _cur = _stream;
     if (getenv("MCN_NO_GRAD_STREAM") == nullptr) {
         chk(mcn_stream_create(&_gradStream), "grad stream");
-        chk(mcn_event_create(&_evFork), "event");
-        chk(mcn_event_create(&_evJoin), "event");
+        chk(mcn_event_create_sync(&_evFork), "event");
+        chk(mcn_event_create_sync(&_evJoin), "event");
     }
     for (auto& l : _layers) l->copyToGPU();
     buildFusions();
@@ -935,8 +937,8 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     if (_dpOn) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
         chk(mcn_stream_create(&_commStream), "comm stream");
-        chk(mcn_event_create(&_evGrad), "event");
-        chk(mcn_event_create(&_evComm), "event");
+        chk(mcn_event_create_sync(&_evGrad), "event");
+        chk(mcn_event_create_sync(&_evComm), "event");
         const char* env = getenv("MCN_BUCKET_MB");
         _bucketFloats = (size_t)((env ? atof(env) : 4.0) * 1024 * 1024 / 4);
         allocate(_minibatchSize);  // every weight matrix now needs a gradient buffer in the arena
@@ -948,17 +950,55 @@ void ConvNet::sync() {
     chk(mcn_stream_sync(_stream), "sync");
 }
 
-void ConvNet::beginGradWork() {
-    if (!_gradStream || _profiling) return;  // profiling times every operation on the main stream
+void ConvNet::deferSideWork(std::function<void()> fn, int units) {
+    if (!_gradStream || _profiling || dataParallel()) {  // profiling times every operation on the main stream;
+        fn();                                            // data-parallel replicas overlap on the exchange stream instead
+        return;
+    }
+    if (_deferredUnits >= 2) flushSideWork(_deferred.size());
+    _deferred.emplace_back(std::move(fn), units);
+    _deferredUnits += units;
+}
+
+void ConvNet::flushSideWork(size_t count) {
+    if (count == 0) return;
     chk(mcn_event_record(_evFork, _stream), "event record");
     chk(mcn_stream_wait_event(_gradStream, _evFork), "wait event");
     _cur = _gradStream;
     _gradPending = true;
+    try {
+        for (size_t i = 0; i < count; i++) {
+            _deferred[i].first();
+            _deferredUnits -= _deferred[i].second;
+        }
+    } catch (...) {
+        _cur = _stream;
+        _deferred.clear();
+        _deferredUnits = 0;
+        throw;
+    }
+    _cur = _stream;
+    _deferred.erase(_deferred.begin(), _deferred.begin() + count);
 }
 
-void ConvNet::endGradWork() { _cur = _stream; }
+void ConvNet::finishSideWork() {
+    // what is still deferred has no backward-data work left to hide behind: half goes to the side stream, the
+    // rest runs on the main stream next to it
+    if (_deferredUnits >= 2) {
+        size_t cut = 0;
+        for (int units = 0; cut < _deferred.size() && units < _deferredUnits / 2; cut++) units += _deferred[cut].second;
+        flushSideWork(cut);
+    }
+    joinGradWork();
+}
 
 void ConvNet::joinGradWork() {
+    if (!_deferred.empty()) {
+        auto rest = std::move(_deferred);
+        _deferred.clear();
+        _deferredUnits = 0;
+        for (auto& d : rest) d.first();  // on the main stream
+    }
     if (!_gradPending) return;
     chk(mcn_event_record(_evJoin, _gradStream), "event record");
     chk(mcn_stream_wait_event(_stream, _evJoin), "wait event");
@@ -990,8 +1030,8 @@ void ConvNet::fprop(int miniIdx, PassType pt) {  // convnet.cu:229-233
 void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
     for (CostLayer* c : _costs) c->bprop(pt);
     for (auto& l : _layers) l->reset();
+    finishSideWork();
     if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
-    joinGradWork();
 }
 
 void ConvNet::updateWeights() {  // convnet.cu:190-194
@@ -1027,7 +1067,7 @@ void ConvNet::flushBuckets(bool force) {
     }
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
-    chk(mcn_event_record(_evGrad, _gradPending ? _gradStream : _stream), "event record");
+    chk(mcn_event_record(_evGrad, _stream), "event record");
     chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
     chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
     _sentUpTo = end;

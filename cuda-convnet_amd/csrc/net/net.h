@@ -458,9 +458,13 @@ class ConvNet {
     void* mainStream() const { return _stream; }
     // Weight / bias gradients of a layer depend only on its incoming gradient, so they run on a side stream
     // next to the backward-data chain (joined before the update, before anything overwrites their inputs).
-    void beginGradWork();
-    void endGradWork();
-    void joinGradWork();
+    // Work that nothing on the backward-data chain waits for (a layer's weight / bias gradients: units = 1; the
+    // cost VALUE kernels: units = 0) is deferred and sent to the side stream two layers at a time -- a cross-stream
+    // dependency costs ~12 us of host time, a launch ~3 -- and what is left when backward ends is split
+    // between the side stream and the main stream.
+    void deferSideWork(std::function<void()> fn, int units);
+    void finishSideWork();   // end of backward: place the remaining work, then join
+    void joinGradWork();     // run whatever is still deferred on the main stream and wait for the side stream
     int numCases() const { return _numCases; }
     int worldSize() const { return _world; }
     int rank() const { return _rank; }
@@ -500,6 +504,9 @@ class ConvNet {
     void* _evFork = nullptr;
     void* _evJoin = nullptr;
     bool _gradPending = false;
+    std::vector<std::pair<std::function<void()>, int>> _deferred;
+    int _deferredUnits = 0;
+    void flushSideWork(size_t count);  // first `count` deferred items -> side stream (one fork)
     DBuf _ws, _ws2;
     DBuf _gradArena;
     DBuf _costBuf;  // doubles, viewed as floats x2

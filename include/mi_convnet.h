@@ -67,6 +67,7 @@ int mcn_stream_destroy(void* stream);
 int mcn_stream_sync(void* stream);
 int mcn_device_sync(void);
 int mcn_event_create(void** event);
+int mcn_event_create_sync(void** event);               /* no timing: for stream ordering only */
 int mcn_event_destroy(void* event);
 int mcn_event_record(void* event, void* stream);
 int mcn_event_sync(void* event);
