@@ -23,7 +23,7 @@ struct FwdParams {
     const float* biases;
     float* targets;
     int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups;
-    int conv, check, biasPerModule, neuron;
+    int conv, check, biasPerModule, neuron, mw;
     float sT, sO, na, nb;
 };
 
@@ -197,6 +197,182 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared-weight conv, fast path.  One wave owns 16*FV filters x 64 images x a strip of `mw` consecutive
+// modules and walks (module, k-batch) as one software-pipelined sequence: the loads of step t+1 are in
+// flight while step t multiplies, across module boundaries too.  All global accesses are buffer
+// instructions (128-bit resource in SGPRs + 32-bit per-lane byte offset + scalar offset), so the per-lane
+// offsets are computed once per wave and a load / store costs ONE instruction: at one or two waves per SIMD
+// a wave retires a vector instruction every 4-8 cycles, and address arithmetic, not MFMA, was the bound.
+// Out-of-range offsets (images beyond N, padded k, padding pixels in CHECK mode) read as zero / are dropped
+// by the hardware range check.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// (hipcc of ROCm 7.2 lowers the b64 / b96 buffer-load builtins to ONE dword replicated into every component,
+// so only the b32 and b128 forms are used)
+template <int FV>
+__device__ __forceinline__ AVec<FV> buf_load_avec(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    AVec<FV> a;
+    if constexpr (FV == 4) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+#pragma unroll
+        for (int i = 0; i < 4; i++) a.v[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < FV; i++) a.v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + 4 * i, soff, 0));
+    }
+    return a;
+}
+
+template <int FV, int UB, bool CHECK, bool RELU>
+__global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
+    extern __shared__ int tbl[];
+    constexpr int KB = 4 * UB;
+    const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
+    const int K = fc * fp, nb = (K + KB - 1) / KB, Kpad = nb * KB, M = p.mY * p.mX;
+    const int imgPixels = p.imgY * p.imgX;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        if (k < K) {
+            const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
+            tbl[2 * k] = (c * imgPixels + fy * p.imgX + fx) * p.imgStride * 4;  // byte offset of the patch row
+            tbl[2 * k + 1] = (fy << 16) | fx;
+        } else {
+            tbl[2 * k] = 0;  // the weight row of a padded k is out of range and reads as zero
+            tbl[2 * k + 1] = 0;
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int mBeg = (blockIdx.y * 4 + wave) * p.mw, mEnd = min(M, mBeg + p.mw);
+    if (mBeg >= M) return;
+    const int n0 = blockIdx.x * 64, f0 = blockIdx.z * (16 * FV), grp = f0 / fpg;
+    const int n = n0 + 4 * j;
+
+    // resources: this group's image channels, the filters, the targets
+    const size_t imgBytes = ((size_t)(fc * imgPixels - 1) * p.imgStride + p.N) * 4;
+    const __amdgpu_buffer_rsrc_t rImg =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.images + (size_t)grp * fc * imgPixels * p.imgStride), 0, (int)imgBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.filters, 0, K * p.F * 4, 0x00020000);
+    const unsigned OOB = 0xFFFFFFF0u;
+    const unsigned laneB = n < p.N ? (unsigned)n * 4u : OOB;           // image quad of this lane
+    const unsigned laneA = (unsigned)(kk * p.F + f0 + FV * j) * 4u;     // weight row k0+kk, filters f0+FV*j..
+
+    float biasv[FV][4];
+    unsigned outOff[FV][4];
+#pragma unroll
+    for (int u = 0; u < FV; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = f0 + FV * (4 * kk + r) + u;
+            biasv[u][r] = p.biases ? p.biases[f] : 0.f;
+            outOff[u][r] = (unsigned)(((size_t)f * M * p.N + n) * 4);
+        }
+
+    f32x4 acc[FV][4];
+#pragma unroll
+    for (int u = 0; u < FV; u++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    AVec<FV> a0[UB], a1[UB];
+    f32x4 b0[UB], b1[UB];
+    // load cursor (module, batch) and compute cursor; module coordinates are wave-uniform
+    int lm = mBeg, lb = 0, lmy = mBeg / p.mX, lmx = mBeg % p.mX;
+    int cm = mBeg, cb = 0;
+    auto load = [&](AVec<FV>(&a)[UB], f32x4(&b)[UB]) {
+        const int y0 = p.pad + lmy * p.stride, x0 = p.pad + lmx * p.stride;
+        const int modBase = (y0 * p.imgX + x0) * p.imgStride * 4;  // may be negative with padding (CHECK)
+        const int kbase = lb * KB;
+#pragma unroll
+        for (int s = 0; s < UB; s++) {
+            const int k = kbase + 4 * s + kk;
+            a[s] = buf_load_avec<FV>(rW, laneA, (unsigned)((kbase + 4 * s) * p.F * 4));
+            unsigned voff = laneB + (unsigned)tbl[2 * k];
+            if (CHECK) {
+                const int yx = tbl[2 * k + 1];
+                const bool inb = (unsigned)(y0 + (yx >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx & 0xffff)) < (unsigned)p.imgX;
+                voff = (inb && laneB != OOB) ? voff + (unsigned)modBase : OOB;
+                b[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rImg, voff, 0, 0));
+            } else {
+                b[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rImg, voff, (unsigned)modBase, 0));
+            }
+        }
+        if (++lb == nb) {
+            lb = 0;
+            lm++;
+            if (++lmx == p.mX) { lmx = 0; lmy++; }
+        }
+    };
+    auto compute = [&](const AVec<FV>(&a)[UB], const f32x4(&b)[UB]) {
+        // the first k-step of a module starts from C = 0 (an inline constant of the MFMA: no accumulator reset)
+        if (cb == 0) {
+#pragma unroll
+            for (int u = 0; u < FV; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[u][t] = mfma16(a[0].v[u], b[0][t], (f32x4){0.f, 0.f, 0.f, 0.f});
+        } else {
+#pragma unroll
+            for (int u = 0; u < FV; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[u][t] = mfma16(a[0].v[u], b[0][t], acc[u][t]);
+        }
+#pragma unroll
+        for (int s = 1; s < UB; s++)
+#pragma unroll
+            for (int u = 0; u < FV; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[u][t] = mfma16(a[s].v[u], b[s][t], acc[u][t]);
+        if (++cb == nb) {
+            // module finished: bias, neuron, store (D row 4kk+r of MFMA u <-> filter f0+FV*(4kk+r)+u; col j, MFMA t <-> image n+t)
+            // plain global stores (uniform module base + the lane's 32-bit offset): with buffer stores hipcc 7.2
+            // reused the data registers in the very next VALU instruction and the last lanes stored the next row
+            char* mbase = reinterpret_cast<char*>(p.targets + (size_t)cm * p.N);
+            if (n < p.N) {
+#pragma unroll
+                for (int u = 0; u < FV; u++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        f32x4 v;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) v[t] = p.sO * acc[u][t][r] + biasv[u][r];
+                        if (RELU) {  // other neurons run as their own kernel after this one (host side)
+#pragma unroll
+                            for (int t = 0; t < 4; t++) v[t] = fmaxf(v[t], 0.f);
+                        }
+                        f32x4* dst = reinterpret_cast<f32x4*>(mbase + outOff[u][r]);
+                        if (p.sT != 0.f) v += p.sT * *dst;
+                        *dst = v;
+                    }
+            }
+            cb = 0;
+            cm++;
+        }
+    };
+    load(a0, b0);
+    while (true) {
+        if (lm < mEnd) load(a1, b1);
+        compute(a0, b0);
+        if (cm >= mEnd) break;
+        if (lm < mEnd) load(a0, b0);
+        compute(a1, b1);
+        if (cm >= mEnd) break;
+    }
+}
+
+template <int FV, int UB>
+static void launch_fast2(const FwdParams& p, dim3 grid, size_t lds, hipStream_t s) {
+    const bool relu = p.neuron == MCN_NEURON_RELU;
+    if (p.check) {
+        if (relu) hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, true, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, true, false>), grid, dim3(256), lds, s, p);
+    } else {
+        if (relu) hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, false, true>), grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, false, false>), grid, dim3(256), lds, s, p);
+    }
+}
+
 template <int FV, int NQ, int U>
 static void launch_fwd3(const FwdParams& p, dim3 grid, size_t lds, bool vecn, bool ksplit, hipStream_t s) {
     if (ksplit) {
@@ -264,6 +440,33 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
 
     const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)targets) % 16 == 0);
     const int ftiles = fpg / 16;
+    p.mw = 1;
+    // fast path (shared weights, 16-byte image accesses, one bias per filter, offsets within 2 GB)
+    if (conv && vecn && !(biases && biasPerModule) && ((uintptr_t)filters % 16 == 0) &&
+        (neuron == MCN_NEURON_IDENT || neuron == MCN_NEURON_RELU) &&
+        (size_t)C * imgY * imgX * imgStride * 4 < (1u << 31) && (size_t)F * M * N * 4 < (1u << 31) && K * F * 4 < (1 << 30)) {
+        p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY);
+        const int ntiles = divup(N, 64);
+        int FV = 1;
+        for (int fv = 4; fv > 1; fv--)
+            if (ftiles % fv == 0 && (long)ntiles * M * (F / (16 * fv)) >= 2048) { FV = fv; break; }
+        const long waves1 = (long)ntiles * M * (F / (16 * FV));
+        p.mw = (int)std::max<long>(1, std::min<long>(8, waves1 / 2560));
+        const int S = divup(K, 4);
+        const int UB = (FV <= 2 && S % 12 == 0) ? 12 : (FV == 4 ? 6 : (FV == 1 ? 16 : 8));
+        dim3 grid(ntiles, divup(divup(M, p.mw), 4), F / (16 * FV));
+        MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "filterActs: grid too large");
+        const size_t lds = (size_t)divup(K, 4 * UB) * 4 * UB * 8;
+        MCN_REQUIRE(lds <= 64 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
+        hipStream_t s = (hipStream_t)stream;
+        if (FV == 4) launch_fast2<4, 6>(p, grid, lds, s);
+        else if (FV == 3) launch_fast2<3, 8>(p, grid, lds, s);
+        else if (FV == 2 && UB == 12) launch_fast2<2, 12>(p, grid, lds, s);
+        else if (FV == 2) launch_fast2<2, 8>(p, grid, lds, s);
+        else if (UB == 12) launch_fast2<1, 12>(p, grid, lds, s);
+        else launch_fast2<1, 16>(p, grid, lds, s);
+        return MCN_LAUNCH_CHECK("filterActs");
+    }
     auto best_fv = [&](int cap) {
         for (int fv = cap; fv > 1; fv--)
             if (ftiles % fv == 0) return fv;

@@ -24,6 +24,10 @@ GEOMS = {
     'conv1_39x31': (39, 31, 3, 16, 4, 36, 28, 0, 1, 1, True),
     'conv1_plus': (55, 55, 3, 32, 4, 52, 52, 0, 1, 1, True),
     'conv2': (26, 26, 16, 32, 3, 24, 24, 0, 1, 1, True),
+    'conv2_plus': (26, 26, 32, 128, 3, 24, 24, 0, 1, 1, True),
+    'local3_plus': (12, 12, 128, 128, 3, 10, 10, 0, 1, 1, False),
+    'conv_f48': (20, 20, 8, 48, 3, 18, 18, 0, 1, 1, True),
+    'conv_f64_pad': (24, 24, 4, 64, 5, 24, 24, -2, 1, 1, True),
     'conv2_39x31': (18, 14, 16, 32, 3, 16, 12, 0, 1, 1, True),
     'local3': (12, 12, 32, 48, 3, 10, 10, 0, 1, 1, False),
     'local3_39x31': (8, 6, 32, 48, 3, 6, 4, 0, 1, 1, False),
