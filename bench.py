@@ -154,6 +154,11 @@ def main():
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
         sys.exit('--gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
 
+    # stdout carries exactly one JSON line: whatever native libraries print (RCCL's version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
 
     import ccn_loader
@@ -226,7 +231,8 @@ def main():
             out['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.workload)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     group.barrier()
     group.close()
 

@@ -80,7 +80,7 @@ MCN_API int mcn_event_elapsed_ms(float* ms, void* start, void* stop) {
 
 // ---------------------------------------------------------------------------
 // RCCL, loaded on first use so that single-GPU users never pay for it.
-// Only the five entry points below are bound (signatures from rccl.h).
+// Only the entry points below are bound (signatures from rccl.h).
 // ---------------------------------------------------------------------------
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
@@ -91,6 +91,8 @@ static struct {
     int (*CommDestroy)(rcclComm_t);
     int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
     int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
+    int (*GroupStart)();
+    int (*GroupEnd)();
     const char* (*GetErrorString)(int);
 } g_rccl;
 
@@ -117,6 +119,8 @@ static int rccl_load() {
     BIND(CommDestroy, "ncclCommDestroy");
     BIND(AllReduce, "ncclAllReduce");
     BIND(AllGather, "ncclAllGather");
+    BIND(GroupStart, "ncclGroupStart");
+    BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
     g_rccl.handle = h;
@@ -165,3 +169,15 @@ MCN_API int mcn_allgather(void* comm, const float* send, float* recv, size_t cou
     MCN_REQUIRE(g_rccl.handle && comm, "mcn_allgather: communicator not initialised");
     return rccl_check(g_rccl.AllGather(send, recv, countPerRank, 7, (rcclComm_t)comm, (hipStream_t)stream), "ncclAllGather");
 }
+
+// collectives issued between the two calls are fused by RCCL into one launch
+MCN_API int mcn_comm_group_begin() {
+    MCN_REQUIRE(g_rccl.handle, "mcn_comm_group_begin: communicator not initialised");
+    return rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+}
+
+MCN_API int mcn_comm_group_end() {
+    MCN_REQUIRE(g_rccl.handle, "mcn_comm_group_end: communicator not initialised");
+    return rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+}
+

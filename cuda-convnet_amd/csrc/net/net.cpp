@@ -654,12 +654,12 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         const int G = _net->worldSize();
         _gathered.ensure((size_t)2 * h * G);
         chk(mcn_l2sn_pair_stats(_inputs[0], _inputs[1], _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
-        _net->allGather(_pairStats.p, _gathered.p, h);
-        _net->allGather(_pairStats.p + h, _gathered.p + (size_t)h * G, h);
+        _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
         _extCount = h * G;
     }
     float *idens = _inputs[0], *data = _inputs[1];
     _net->deferSideWork([this, idens, data, D, n] {
+        if (_extCount) _net->waitGather();
         chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
                           _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
     }, 0);
@@ -668,6 +668,7 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
     const int n = _net->numCases(), D = _prev[1]->outputs();
+    if (_extCount) _net->waitGather();
     chk(mcn_l2sn_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), D, n, _m, scaleTargets == 1 ? 1 : 0, _coeff,
                       _extCount ? _gathered.p : nullptr, _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()),
         "l2sn grad");
@@ -785,6 +786,8 @@ ConvNet::~ConvNet() {
     if (_comm) mcn_comm_destroy(_comm);
     if (_commStream) mcn_stream_destroy(_commStream);
     if (_evGrad) mcn_event_destroy(_evGrad);
+    if (_evGrad2) mcn_event_destroy(_evGrad2);
+    if (_evGather) mcn_event_destroy(_evGather);
     if (_evComm) mcn_event_destroy(_evComm);
     if (_gradStream) mcn_stream_destroy(_gradStream);
     if (_evFork) mcn_event_destroy(_evFork);
@@ -938,6 +941,8 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
         chk(mcn_stream_create(&_commStream), "comm stream");
         chk(mcn_event_create_sync(&_evGrad), "event");
+        chk(mcn_event_create_sync(&_evGrad2), "event");
+        chk(mcn_event_create_sync(&_evGather), "event");
         chk(mcn_event_create_sync(&_evComm), "event");
         const char* env = getenv("MCN_BUCKET_MB");
         _bucketFloats = (size_t)((env ? atof(env) : 4.0) * 1024 * 1024 / 4);
@@ -951,8 +956,8 @@ void ConvNet::sync() {
 }
 
 void ConvNet::deferSideWork(std::function<void()> fn, int units) {
-    if (!_gradStream || _profiling || dataParallel()) {  // profiling times every operation on the main stream;
-        fn();                                            // data-parallel replicas overlap on the exchange stream instead
+    if (!_gradStream || _profiling) {  // profiling times every operation on the main stream
+        fn();
         return;
     }
     if (_deferredUnits >= 2) flushSideWork(_deferred.size());
@@ -1067,8 +1072,13 @@ void ConvNet::flushBuckets(bool force) {
     }
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
+    // the bucket's gradients were enqueued on the main stream or on the gradient side stream: wait for both
     chk(mcn_event_record(_evGrad, _stream), "event record");
     chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
+    if (_gradPending) {
+        chk(mcn_event_record(_evGrad2, _gradStream), "event record");
+        chk(mcn_stream_wait_event(_commStream, _evGrad2), "wait event");
+    }
     chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
     _sentUpTo = end;
     _commPending = true;
@@ -1084,12 +1094,19 @@ void ConvNet::waitComm() {
     for (Segment& s : _segments) s.ready = false;
 }
 
-void ConvNet::allGather(const float* send, float* recv, size_t countPerRank) {
+void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
+    // both gathers in one fused RCCL launch on the exchange stream; consumers call waitGather() when they need the result
     chk(mcn_event_record(_evGrad, _stream), "event record");
     chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
-    chk(mcn_allgather(_comm, send, recv, countPerRank, _commStream), "all-gather");
-    chk(mcn_event_record(_evComm, _commStream), "event record");
-    chk(mcn_stream_wait_event(_stream, _evComm), "wait event");
+    chk(mcn_comm_group_begin(), "group begin");
+    chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
+    chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
+    chk(mcn_comm_group_end(), "group end");
+    chk(mcn_event_record(_evGather, _commStream), "event record");
+}
+
+void ConvNet::waitGather() {  // on the stream the caller is enqueueing on
+    chk(mcn_stream_wait_event(_cur, _evGather), "wait event");
 }
 
 // ---- per-operation event timing -----------------------------------------------------------------

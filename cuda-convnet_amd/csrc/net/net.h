@@ -475,7 +475,8 @@ class ConvNet {
     int numLayers() const { return (int)_layers.size(); }
     DataProvider& dp() { return *_dp; }
     void gradReady(WeightLayer* l);             // data-parallel: layer's gradient segment is complete
-    void allGather(const float* send, float* recv, size_t countPerRank);  // on the compute stream order
+    void allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // starts on the exchange stream
+    void waitGather();
     void setFusion(bool on) { _fusion = on; }
     bool profiling() const { return _profiling; }
     void profBegin(const std::string& label);
@@ -521,6 +522,8 @@ class ConvNet {
     void* _comm = nullptr;
     void* _commStream = nullptr;
     void* _evGrad = nullptr;
+    void* _evGrad2 = nullptr;
+    void* _evGather = nullptr;
     void* _evComm = nullptr;
     struct Segment { WeightLayer* layer; size_t begin, end; bool ready; };
     std::vector<Segment> _segments;  // in arena order (reverse layer order)

@@ -281,6 +281,9 @@ int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]);
 int mcn_comm_destroy(void* comm);
 int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream);
 int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream);
+/* collectives issued between begin and end are fused into one launch (ncclGroupStart / ncclGroupEnd) */
+int mcn_comm_group_begin(void);
+int mcn_comm_group_end(void);
 
 #ifdef __cplusplus
 }
