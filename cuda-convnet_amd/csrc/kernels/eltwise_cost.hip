@@ -712,6 +712,37 @@ MCN_API int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarg
                           float coeff, const float* extDists, const float* extLabels, int extCount, void* stream) {
     return l2sn_launch(1, idens, data, dataTarget, numD, numCases, m, add, coeff, nullptr, nullptr, nullptr, extDists, extLabels, extCount, stream);
 }
+// Gradient from pair statistics and a margin that an earlier l2sn cost launch left in device memory: purely
+// elementwise (one gallery/probe element pair per thread), same arithmetic as k_l2sn<1>.
+__global__ __launch_bounds__(256) void k_l2sn_grad_stats(const float* __restrict__ data, float* __restrict__ out, int numD, int numCases,
+                                                          const float* __restrict__ stats, const float* __restrict__ info, int add,
+                                                          float coeff) {
+    const int h = numCases / 2;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int k = e / h, j = e - k * h;
+    if (k >= numD) return;
+    const float m = info[0], dist = stats[j], lab = stats[h + j];
+    const float posMask = 0.5f * lab + 0.5f, negMask1 = -0.5f * lab + 0.5f;
+    const float negMask2 = dist < m ? 1.f : 0.f;
+    const float r = __fadd_rn(__fmul_rn(1.0f / dist, m), -1.0f);
+    const float s1 = data[(size_t)k * numCases + j], s2 = data[(size_t)k * numCases + j + h];
+    const float diff1 = s1 - s2, diff2 = s2 - s1;
+    const float gx = __fadd_rn(__fmul_rn(diff2, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff1, r), negMask1), negMask2));
+    const float gy = __fadd_rn(__fmul_rn(diff1, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff2, r), negMask1), negMask2));
+    float* tg = out + (size_t)k * numCases + j;
+    float* tp = tg + h;
+    *tg = add ? __fadd_rn(*tg, __fmul_rn(gx, coeff)) : __fmul_rn(gx, coeff);
+    *tp = add ? __fadd_rn(*tp, __fmul_rn(gy, coeff)) : __fmul_rn(gy, coeff);
+}
+MCN_API int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int numD, int numCases, const float* pairStats,
+                                     const float* info, int add, float coeff, void* stream) {
+    MCN_REQUIRE(data && dataTarget && pairStats && info && numD > 0 && numCases > 0, "l2snGradFromStats: bad argument");
+    MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");
+    const size_t elems = (size_t)numD * (numCases / 2);
+    hipLaunchKernelGGL(k_l2sn_grad_stats, dim3((unsigned)divup_sz(elems, 256)), dim3(256), 0, (hipStream_t)stream, data, dataTarget, numD,
+                       numCases, pairStats, info, add, coeff);
+    return MCN_LAUNCH_CHECK("l2snGradFromStats");
+}
 MCN_API int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream) {
     MCN_REQUIRE(pairStats, "l2snPairStats: null pointer");
     return l2sn_launch(2, idens, data, nullptr, numD, numCases, 1.f, 0, 0.f, nullptr, pairStats, nullptr, nullptr, nullptr, 0, stream);

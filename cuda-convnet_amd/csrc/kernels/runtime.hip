@@ -45,6 +45,32 @@ MCN_API int mcn_copy2d(void* dst, size_t dpitch, const void* src, size_t spitch,
     hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     return mcn_check_hip(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, k, (hipStream_t)stream), "hipMemcpy2DAsync");
 }
+// Every minibatch column slice of a resident data batch in one pass: dst = [minibatch index][rows][columns of that
+// minibatch], so that the per-step slice (data.cu:72-98) is a pointer.  One thread per column (VEC = 4: per 4 columns).
+template <int VEC>
+__global__ __launch_bounds__(256) void k_tile_minibatches(const float* __restrict__ src, float* __restrict__ dst, int rows, long numCases,
+                                                           int minibatch) {
+    const long c = ((long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (c >= numCases) return;
+    const long mi = c / minibatch, c0 = mi * minibatch;
+    const long n = numCases - c0 < minibatch ? numCases - c0 : minibatch;  // columns of this (maybe last, ragged) minibatch
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const float* sp = src + (size_t)r * numCases + c;
+        float* dp = dst + (size_t)c0 * rows + (size_t)r * n + (c - c0);
+        if (VEC == 4) *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+        else *dp = *sp;
+    }
+}
+MCN_API int mcn_tile_minibatches(const float* src, float* dst, int rows, size_t numCasesSz, int minibatch, void* stream) {
+    const long numCases = (long)numCasesSz;
+    MCN_REQUIRE(src && dst && rows > 0 && numCases > 0 && minibatch > 0, "tileMinibatches: bad argument");
+    const bool vec = minibatch % 4 == 0 && numCases % 4 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
+    const long cols = vec ? numCases / 4 : numCases;
+    dim3 grid((unsigned)((cols + 255) / 256), (unsigned)std::min(rows, 4096));
+    if (vec) hipLaunchKernelGGL((k_tile_minibatches<4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
+    else hipLaunchKernelGGL((k_tile_minibatches<1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
+    return MCN_LAUNCH_CHECK("tileMinibatches");
+}
 MCN_API int mcn_stream_create(void** stream) {
     hipStream_t s;
     int rc = mcn_check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");

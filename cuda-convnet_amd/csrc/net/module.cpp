@@ -199,7 +199,7 @@ static PyObject* startSteps(PyObject*, PyObject* args) {
     if (!PyArg_ParseTuple(args, "i|ii", &numSteps, &test, &profile)) return nullptr;
     if (!needModel()) return nullptr;
     inflight.emplace_back();
-    model->workQueue().enqueue([numSteps, test, profile](ConvNet& n) { n.runSteps(numSteps, test != 0, profile != 0); });
+    model->workQueue().enqueue([numSteps, test, profile](ConvNet& n) { n.runSteps(numSteps, test != 0, profile); });
     return Py_BuildValue("i", 0);
 }
 

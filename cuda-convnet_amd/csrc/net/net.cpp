@@ -269,11 +269,16 @@ float WeightLayer::gradScale(float eps, PassType pt) const {
 }
 
 void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
+    // two pieces of side-stream work: they start at once next to this layer's backward-data kernels, except for the
+    // last weight layer of the pass, which has nothing left to hide behind and is split over both streams
+    const bool last = _net->lastWeightLayerOfPass();
     _net->deferSideWork([this, v, pt] {
         if (_biases->eps() > 0) {
             ProfScope ps(_net, _name, "bpropBiases");
             bpropBiases(v, pt);
         }
+    }, 1, true);
+    _net->deferSideWork([this, v, pt] {
         for (int i = 0; i < (int)_weights.size(); i++) {
             if (_weights[i]->eps() > 0) {
                 ProfScope ps(_net, _name, "bpropWeights", i);
@@ -282,7 +287,7 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
             }
         }
         if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
-    }, 1);
+    }, 1, last);
 }
 
 void WeightLayer::updateWeights() {
@@ -638,40 +643,47 @@ void SumOfSquaresCostLayer::bpropActs(float*, int i, float scaleTargets, PassTyp
 
 L2SNCostLayer::L2SNCostLayer(ConvNet* net, const Params& p) : CostLayer(net, p) { _m = (float)pfloat(p, "m"); }  // layer.cu:1055-1058
 
+L2SNCostLayer::~L2SNCostLayer() {
+    if (_evReady) mcn_event_destroy(_evReady);
+}
+
 void L2SNCostLayer::allocate(int maxCases) {
     CostLayer::allocate(maxCases);
     _pairStats.ensure(std::max(maxCases, 4));
+    _info.ensure(4);
     _gathered.ensure((size_t)std::max(maxCases, 4) * std::max(1, _net->worldSize()));
+    if (!_evReady) chk(mcn_event_create_sync(&_evReady), "event");
 }
 
+// The pair statistics, the margin search and the cost run on the side stream as soon as the features exist, next to
+// the rest of the forward pass; the backward pass waits for them and is then one elementwise launch.
 void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
     if (i != 0) return;
     const int n = _net->numCases(), D = _prev[1]->outputs(), h = n / 2;
-    _extCount = 0;
-    if (_net->dataParallel() && _m < 0) {
-        // the data-dependent margin must be the one a single GPU would pick on the global minibatch
-        // (SURVEY 8e): gather every rank's pair distances and labels, search over all of them
-        const int G = _net->worldSize();
-        _gathered.ensure((size_t)2 * h * G);
-        chk(mcn_l2sn_pair_stats(_inputs[0], _inputs[1], _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
-        _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
-        _extCount = h * G;
-    }
+    // data parallel: the data-dependent margin must be the one a single GPU would pick on the global minibatch
+    // (SURVEY 8e): gather every rank's pair distances and labels, search over all of them
+    const bool gather = _net->dataParallel() && _m < 0;
+    const int G = _net->worldSize();
+    _extCount = gather ? h * G : 0;
+    if (gather) _gathered.ensure((size_t)2 * h * G);
     float *idens = _inputs[0], *data = _inputs[1];
-    _net->deferSideWork([this, idens, data, D, n] {
-        if (_extCount) _net->waitGather();
-        chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, nullptr, nullptr, dCost, _extCount ? _gathered.p : nullptr,
-                          _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
-    }, 0);
+    _net->forkSideWork([this, idens, data, D, n, h, G, gather] {
+        if (gather) {
+            chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
+            _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
+            _net->waitGather();
+        }
+        chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, gather ? nullptr : _pairStats.p, dCost, gather ? _gathered.p : nullptr,
+                          gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+        chk(mcn_event_record(_evReady, _net->stream()), "event record");
+    });
 }
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
-    const int n = _net->numCases(), D = _prev[1]->outputs();
-    if (_extCount) _net->waitGather();
-    chk(mcn_l2sn_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), D, n, _m, scaleTargets == 1 ? 1 : 0, _coeff,
-                      _extCount ? _gathered.p : nullptr, _extCount ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()),
-        "l2sn grad");
+    chk(mcn_stream_wait_event(_net->stream(), _evReady), "wait event");
+    chk(mcn_l2sn_grad_from_stats(_prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(), _pairStats.p,
+                                 _info.p, scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2sn grad");
 }
 
 void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
@@ -703,6 +715,7 @@ void DataProvider::setData(const CPUData& d) {
     while (_dev.size() < d.mats.size()) {
         _dev.emplace_back(new DBuf());
         _mini.emplace_back(new DBuf());
+        _tiled.emplace_back(new DBuf());
     }
     // The reference keeps a batch on the device below 200 MB (util.cuh:53) and otherwise uploads a
     // host-side column slice per minibatch.  With 288 GB of HBM the whole batch is resident by default.
@@ -713,6 +726,10 @@ void DataProvider::setData(const CPUData& d) {
         for (size_t i = 0; i < d.mats.size(); i++) {
             _dev[i]->ensure(d.mats[i].size());
             chk(mcn_h2d(_dev[i]->p, d.mats[i].data, d.mats[i].size() * 4, _net->stream()), "h2d data batch");
+            // every minibatch slice laid out densely once per batch: the per-step slice is then a pointer
+            _tiled[i]->ensure(d.mats[i].size());
+            chk(mcn_tile_minibatches(_dev[i]->p, _tiled[i]->p, (int)d.mats[i].rows, (size_t)_numCases, _minibatchSize, _net->stream()),
+                "tile minibatches");
         }
         chk(mcn_stream_sync(_net->stream()), "sync");
     }
@@ -726,6 +743,11 @@ void DataProvider::getSlice(long start, long end, std::vector<float*>& out) {
     for (size_t i = 0; i < _dims.size(); i++) {
         if (_onDevice && n == _numCases) {
             out.push_back(_dev[i]->p);
+            continue;
+        }
+        if (_onDevice && start % _minibatchSize == 0 && end == std::min(start + _minibatchSize, _numCases) &&
+            ((size_t)start * _dims[i]) % 4 == 0) {  // (16-byte aligned like every other activation buffer)
+            out.push_back(_tiled[i]->p + (size_t)start * _dims[i]);
             continue;
         }
         _mini[i]->ensure((size_t)_dims[i] * _minibatchSize);
@@ -863,6 +885,7 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
     chk(mcn_set_device(_deviceID < 0 ? 0 : _deviceID), "set device");
     chk(mcn_stream_create(&_stream), "stream");
     _cur = _stream;
+    if (const char* e = getenv("MCN_SIDE_UNITS")) _sideUnits = std::max(1, atoi(e));
     if (getenv("MCN_NO_GRAD_STREAM") == nullptr) {
         chk(mcn_stream_create(&_gradStream), "grad stream");
         chk(mcn_event_create_sync(&_evFork), "event");
@@ -955,14 +978,26 @@ void ConvNet::sync() {
     chk(mcn_stream_sync(_stream), "sync");
 }
 
-void ConvNet::deferSideWork(std::function<void()> fn, int units) {
+bool ConvNet::lastWeightLayerOfPass() { return ++_wlSeen == _wlPerPass; }
+
+void ConvNet::deferSideWork(std::function<void()> fn, int units, bool hold) {
     if (!_gradStream || _profiling) {  // profiling times every operation on the main stream
         fn();
         return;
     }
-    if (_deferredUnits >= 2) flushSideWork(_deferred.size());
     _deferred.emplace_back(std::move(fn), units);
     _deferredUnits += units;
+    if (!hold && _deferredUnits >= _sideUnits) flushSideWork(_deferred.size());
+}
+
+void ConvNet::forkSideWork(std::function<void()> fn) {
+    if (!_gradStream || _profiling) {
+        fn();
+        return;
+    }
+    flushSideWork(_deferred.size());  // keeps the order of what was deferred before
+    _deferred.emplace_back(std::move(fn), 0);
+    flushSideWork(1);
 }
 
 void ConvNet::flushSideWork(size_t count) {
@@ -1033,9 +1068,17 @@ void ConvNet::fprop(int miniIdx, PassType pt) {  // convnet.cu:229-233
 }
 
 void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
+    if (_phases) profBegin("phase.backward_data_chain");
     for (CostLayer* c : _costs) c->bprop(pt);
+    if (_phases) {
+        profEnd();
+        profBegin("phase.gradient_tail");
+    }
     for (auto& l : _layers) l->reset();
+    _wlPerPass = _wlSeen;  // (the first pass learns how many weight layers a backward pass visits)
+    _wlSeen = 0;
     finishSideWork();
+    if (_phases) profEnd();
     if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
 }
 
@@ -1096,7 +1139,7 @@ void ConvNet::waitComm() {
 
 void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
     // both gathers in one fused RCCL launch on the exchange stream; consumers call waitGather() when they need the result
-    chk(mcn_event_record(_evGrad, _stream), "event record");
+    chk(mcn_event_record(_evGrad, _cur), "event record");
     chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
     chk(mcn_comm_group_begin(), "group begin");
     chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");

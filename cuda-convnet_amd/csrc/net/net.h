@@ -313,13 +313,16 @@ class SumOfSquaresCostLayer : public CostLayer {
 class L2SNCostLayer : public CostLayer {
    public:
     L2SNCostLayer(ConvNet* net, const Params& p);
+    ~L2SNCostLayer() override;
     size_t actsElems(int n) const override { return (size_t)n; }
     void allocate(int maxCases) override;
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
     float _m;
-    DBuf _pairStats, _gathered;  // data-parallel: local (dists, labels) and the all-gathered candidates
+    DBuf _pairStats, _info;  // what the cost launch keeps for the gradient: (dists, labels) and {margin, chosen pair, 0, 0}
+    DBuf _gathered;          // data-parallel: the all-gathered margin candidates
+    void* _evReady = nullptr;  // recorded after the cost launch, on whichever stream ran it
     int _extCount = 0;
 };
 
@@ -356,7 +359,7 @@ class DataProvider {
     long _numCases = 0;
     bool _onDevice = false;
     std::vector<long> _dims;
-    std::vector<std::unique_ptr<DBuf>> _dev, _mini;
+    std::vector<std::unique_ptr<DBuf>> _dev, _mini, _tiled;  // whole batch; one copied slice; all slices, minibatch-major
 };
 
 // ---- costs (cost.cu) ------------------------------------------------------------------------
@@ -451,7 +454,8 @@ class ConvNet {
     void runLoad(const CPUData& data);
     // numSteps minibatches cycling over the resident batch (benchmark / profiling loop: no host data,
     // no allocation, one cost read-back at the end).  profile: bracket every layer operation with events.
-    void runSteps(int numSteps, bool test, bool profile);
+    // profile 2: only the phases of a step (forward / backward-data chain / gradient tail / update), streams as in a normal run.
+    void runSteps(int numSteps, bool test, int profile);
 
     // ---- services for layers ---------------------------------------------------------------
     void* stream() const { return _cur; }       // the stream layer operations are issued on right now
@@ -462,7 +466,8 @@ class ConvNet {
     // cost VALUE kernels: units = 0) is deferred and sent to the side stream two layers at a time -- a cross-stream
     // dependency costs ~12 us of host time, a launch ~3 -- and what is left when backward ends is split
     // between the side stream and the main stream.
-    void deferSideWork(std::function<void()> fn, int units);
+    void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
+    bool lastWeightLayerOfPass();
     void finishSideWork();   // end of backward: place the remaining work, then join
     void joinGradWork();     // run whatever is still deferred on the main stream and wait for the side stream
     int numCases() const { return _numCases; }
@@ -477,6 +482,7 @@ class ConvNet {
     void gradReady(WeightLayer* l);             // data-parallel: layer's gradient segment is complete
     void allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // starts on the exchange stream
     void waitGather();
+    void forkSideWork(std::function<void()> fn);  // starts now, on the side stream
     void setFusion(bool on) { _fusion = on; }
     bool profiling() const { return _profiling; }
     void profBegin(const std::string& label);
@@ -523,6 +529,7 @@ class ConvNet {
     void* _commStream = nullptr;
     void* _evGrad = nullptr;
     void* _evGrad2 = nullptr;
+    int _sideUnits = 2, _wlSeen = 0, _wlPerPass = 0;
     void* _evGather = nullptr;
     void* _evComm = nullptr;
     struct Segment { WeightLayer* layer; size_t begin, end; bool ready; };
@@ -532,7 +539,7 @@ class ConvNet {
     bool _commPending = false;
 
     // per-operation event timing (off on the normal path)
-    bool _profiling = false;
+    bool _profiling = false, _phases = false;
     struct ProfSpan { int label; void* e0; void* e1; };
     std::vector<std::string> _profLabels;
     std::map<std::string, int> _profLabelIdx;

@@ -89,22 +89,27 @@ void ConvNet::runTraining(const CPUData& data, bool test, bool useResident) {
     _results.enqueue(std::move(res));
 }
 
-void ConvNet::runSteps(int numSteps, bool test, bool profile) {
+void ConvNet::runSteps(int numSteps, bool test, int profile) {
     if (!_dp->resident()) throw NetError("no resident data batch: call loadBatch first");
     if (numSteps < 0) throw NetError("negative step count");
     WorkResult res;
     zeroCosts();
-    _profiling = profile;
+    _profiling = profile == 1;
+    _phases = profile == 2;
     const int nm = _dp->numMinibatches();
     long cases = 0;
     const auto t0 = std::chrono::steady_clock::now();
     try {
         for (int s = 0; s < numSteps; s++) {
+            if (_phases) profBegin("phase.forward");
             fprop(s % nm, test ? PASS_TEST : PASS_TRAIN);
+            if (_phases) profEnd();
             cases += _numCases;
             if (!test) {
                 bprop(PASS_TRAIN);
+                if (_phases) profBegin("phase.update");
                 updateWeights();
+                if (_phases) profEnd();
             }
         }
         const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -113,10 +118,10 @@ void ConvNet::runSteps(int numSteps, bool test, bool profile) {
         res.profile["host.enqueue"].count = numSteps;
         res.profile["host.enqueue"].ms = enq;
     } catch (...) {
-        _profiling = false;
+        _profiling = _phases = false;
         throw;
     }
-    _profiling = false;
+    _profiling = _phases = false;
     readCosts(res.cost, cases);
     res.type = WorkResult::BATCH_DONE;
     _results.enqueue(std::move(res));

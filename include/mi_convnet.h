@@ -62,6 +62,10 @@ int mcn_d2d(void* dst, const void* src, size_t bytes, void* stream);
 /* kind: 0 h2d, 1 d2h, 2 d2d.  Column-slice copies (data.cu:72-98 sliceCols). */
 int mcn_copy2d(void* dst, size_t dpitchBytes, const void* src, size_t spitchBytes, size_t widthBytes,
                size_t height, int kind, void* stream);
+/* All minibatch column slices of a resident (rows, numCases) batch at once (data.cu:72-98 run ahead of time):
+ * dst holds, minibatch after minibatch, a dense (rows, n_i) matrix with n_i = min(minibatch, numCases - i*minibatch);
+ * slice i starts at dst + i*minibatch*rows. */
+int mcn_tile_minibatches(const float* src, float* dst, int rows, size_t numCases, int minibatch, void* stream);
 int mcn_stream_create(void** stream);
 int mcn_stream_destroy(void* stream);
 int mcn_stream_sync(void* stream);
@@ -246,6 +250,11 @@ int mcn_l2sn_cost(const float* idens, const float* data, float* output, int numD
 /* computeL2SNGrad (layer_kernels.cu:620-735): dataTarget (numD, numCases) (+)= coeff * grad */
 int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarget, int numD, int numCases, float m,
                   int add, float coeff, const float* extDists, const float* extLabels, int extCount, void* stream);
+/* The same gradient from what a preceding mcn_l2sn_cost on the same inputs left in device memory (pairStats and
+ * info[0] = margin): one elementwise launch, so that the layer's backward pass does not repeat the statistics and
+ * the margin search (layer.cu:1073-1082 calls computeL2SNGrad with the margin its fprop kept). */
+int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int numD, int numCases, const float* pairStats,
+                             const float* info, int add, float coeff, void* stream);
 /* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2] */
 int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream);
 /* computeL2regCost / computeL2regGrad (layer_kernels.cu:744-794) */

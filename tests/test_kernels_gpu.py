@@ -601,6 +601,9 @@ def test_l2sn(D, N, m):
         d_t = dev(t0)
         call('mcn_l2sn_grad', dev(ids), dev(data), d_t, D, N, m, add, 0.0025, None, None, 0, None)
         close(d_t.numpy(), wg, rtol=1e-6, atol=1e-9, what='l2sn grad')
+        d_t2 = dev(t0)
+        call('mcn_l2sn_grad_from_stats', dev(data), d_t2, D, N, d_stats, d_info, add, 0.0025, None)
+        assert np.array_equal(d_t2.numpy(), d_t.numpy()), 'gradient from kept statistics must equal the recomputing kernel bit for bit'
 
 
 def test_l2sn_external_candidates():
@@ -693,3 +696,16 @@ def test_sgd_update_planned_matches_per_matrix_update():
     for (W, inc, g), (dW, dI, dG), spec in zip(host, devs, specs):
         close(dW.numpy(), W, rtol=1e-6, what='W %r' % (spec,))
         close(dI.numpy(), inc, rtol=1e-6, what='inc %r' % (spec,))
+
+
+@pytest.mark.parametrize('rows,cases,mb', [(7, 1000, 128), (1, 64, 128), (3, 130, 34), (9075, 300, 128), (5, 256, 128)])
+def test_tile_minibatches(rows, cases, mb):
+    """Every column slice of data.cu:72-98 at once: slice i is dense (rows, n_i) at offset i*mb*rows."""
+    rng = np.random.default_rng(40)
+    src = rng.standard_normal((rows, cases)).astype(np.float32)
+    d_dst = dev_empty((rows * cases,), np.nan)
+    call('mcn_tile_minibatches', dev(src), d_dst, rows, cases, mb, None)
+    got = d_dst.numpy()
+    for i in range(0, cases, mb):
+        n = min(mb, cases - i)
+        assert np.array_equal(got[i * rows:i * rows + rows * n].reshape(rows, n), src[:, i:i + n])

@@ -23,3 +23,13 @@ bench('launch + record', lambda: (scale(a.ptr, b.ptr, 4, f2, s1), rec(e1, s1)))
 bench('launch, record, wait(other), launch(other)', lambda: (scale(a.ptr, b.ptr, 4, f2, s1), rec(e1, s1), wait(s2, e1), scale(a.ptr, b.ptr, 4, f2, s2)))
 bench('fork + join per iter', lambda: (scale(a.ptr, b.ptr, 4, f2, s1), rec(e1, s1), wait(s2, e1), scale(a.ptr, b.ptr, 4, f2, s2), rec(e2, s2), wait(s1, e2)))
 bench('2 launches, 2 streams, no events', lambda: (scale(a.ptr, b.ptr, 4, f2, s1), scale(a.ptr, b.ptr, 4, f2, s2)))
+# two host threads, one stream each (ctypes releases the GIL inside the call)
+import threading
+def worker(s, n):
+    for _ in range(n): scale(a.ptr, b.ptr, 4, f2, s)
+for nthreads in (1, 2):
+    L.call('mcn_device_sync'); t = time.perf_counter()
+    ths = [threading.Thread(target=worker, args=((s1, s2)[i], 20000)) for i in range(nthreads)]
+    [x.start() for x in ths]; [x.join() for x in ths]
+    dt = time.perf_counter() - t; L.call('mcn_device_sync'); tot = time.perf_counter() - t
+    print('%d thread(s) x 20000 launches, own stream: host %6.2f us per launch per thread, drained %6.2f' % (nthreads, dt / 20000 * 1e6, tot / 20000 * 1e6), flush=True)
