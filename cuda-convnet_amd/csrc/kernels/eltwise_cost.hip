@@ -116,7 +116,21 @@ __global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ mat, 
     const int c0 = chunk * ROWSUM_CHUNK, c1 = min(cols, c0 + ROWSUM_CHUNK);
     const float* m = mat + (size_t)row * cols;
     float v = 0.f;
-    for (int c = c0 + threadIdx.x; c < c1; c += 256) v += m[c];
+    if (cols % 4 == 0 && ((uintptr_t)mat) % 16 == 0) {
+        // the whole chunk in one batch of independent 16-byte loads per thread (one memory round trip)
+        const f32x4* m4 = reinterpret_cast<const f32x4*>(m + c0);
+        const int n4 = (c1 - c0) / 4;
+        f32x4 t[ROWSUM_CHUNK / 1024];
+#pragma unroll
+        for (int u = 0; u < ROWSUM_CHUNK / 1024; u++) {
+            const int i = threadIdx.x + 256 * u;
+            t[u] = i < n4 ? m4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < ROWSUM_CHUNK / 1024; u++) v += (t[u][0] + t[u][1]) + (t[u][2] + t[u][3]);
+    } else {
+        for (int c = c0 + threadIdx.x; c < c1; c += 256) v += m[c];
+    }
     const float s = block_sum256(v, sh);
     if (threadIdx.x == 0) {
         if (finalStage) out[row] = (scaleThis != 0.f ? scaleThis * out[row] : 0.f) + scaleSum * s;
@@ -292,6 +306,7 @@ __global__ __launch_bounds__(256) void k_softmax_partial(const float* __restrict
 // 16 columns x 16 merge lanes per block: lane g merges chunks g, g+16, ... (one batch of independent loads),
 // the 16 lanes are combined through LDS in a fixed order, then the block writes its 64 rows x 16 columns.
 #define SMF_COLS 16
+#define SMF_ROWS 256  // rows per block of k_softmax_final
 #define SMF_MAXB 16  // chunks per merge lane held in registers per batch
 __device__ __forceinline__ void softmax_merge16(const f32x2* pp, int numCases, int chunks, int col, bool live, int g, int cl,
                                                 float (*shm)[SMF_COLS], float (*shs)[SMF_COLS], float& M, float& S) {
@@ -330,15 +345,16 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
     float M, S;
     softmax_merge16(reinterpret_cast<const f32x2*>(part), numCases, chunks, col, live, g, cl, shm, shs, M, S);
     if (!live) return;
-    const int r0 = chunk * SM_ROWS;
-    float v[SM_ROWS / 16];
+    // a block normalises SMF_ROWS rows of its 16 columns, so that the merge above is repeated by few blocks
+    const int r0 = chunk * SMF_ROWS;
+    float v[SMF_ROWS / 16];
 #pragma unroll
-    for (int i = 0; i < SM_ROWS / 16; i++) {
+    for (int i = 0; i < SMF_ROWS / 16; i++) {
         const int r = r0 + g + 16 * i;
         v[i] = r < numOut ? x[(size_t)r * numCases + col] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < SM_ROWS / 16; i++) {
+    for (int i = 0; i < SMF_ROWS / 16; i++) {
         const int r = r0 + g + 16 * i;
         if (r < numOut) p[(size_t)r * numCases + col] = expf(v[i] - M) / S;
     }
@@ -358,7 +374,7 @@ MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, 
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(divup(numCases, 64), chunks);
     hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
-    hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), chunks), dim3(256), 0, s, x, probs, (const float*)workspace, numOut,
+    hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, (const float*)workspace, numOut,
                        numCases, chunks);
     return MCN_LAUNCH_CHECK("softmax");
 }
