@@ -104,7 +104,7 @@ def roofline_entry(layers, label, count, ms, N):
     return e
 
 
-def cpu_baseline(preset, budget_s=15.0):
+def cpu_baseline(preset, budget_s=12.0):
     """The whole-net CPU oracle on a bounded sample of the same workload (images/sec on host cores)."""
     import ccn_loader
     ccn_loader.load()
@@ -122,7 +122,7 @@ def cpu_baseline(preset, budget_s=15.0):
     t0 = time.time()
     net.run_batch(data)
     one = time.time() - t0
-    reps = int(max(1, min(32, budget_s / max(one, 1e-3))))
+    reps = int(max(1, min(512, budget_s / max(one, 1e-3))))  # ~12 s of CPU work
     t0 = time.time()
     for _ in range(reps):
         net.run_batch(data)

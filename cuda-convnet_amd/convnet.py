@@ -160,6 +160,7 @@ PRESETS = {  # name: (layer def, layer params, provider kind, image geometry)
     'deepid': ('deepid_4213.cfg', 'deepid_params.cfg', 'deepid', (55, 55, 3)),
     'deepid-39x31': ('deepid_4213_39x31.cfg', 'deepid_params.cfg', 'deepid', (39, 31, 3)),
     'deepid2': ('deepid2_10575.cfg', 'deepid_params.cfg', 'deepid2', (55, 55, 3)),
+    'deepidn': ('deepidn_10575.cfg', 'deepidn_params.cfg', 'deepid2', (55, 55, 3)),  # DeepID2 + cost.fisher2 (deepidn/*.cfg)
     'deepid2plus': ('deepid2plus_10575.cfg', 'deepid_params.cfg', 'deepid2', (55, 55, 3)),
     'deepid-attr': ('deepid_attr_4131.cfg', 'deepid_attr_params.cfg', 'deepid_attr', (55, 55, 3)),
     'cifar10': ('cifar10.cfg', 'cifar10_params.cfg', 'cifar', (32, 32, 3)),

@@ -910,3 +910,153 @@ MCN_API int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlo
     hipLaunchKernelGGL(k_sgd_planned, dim3(numBlocks), dim3(256), 0, (hipStream_t)stream, (const SgdRec*)devicePlan, count);
     return MCN_LAUNCH_CHECK("sgdUpdatePlanned");
 }
+
+// ---------------------------------------------------------------- Fisher2 cost (layer_kernels.cu:310-479)
+// Workspace (floats): E[N*N] squared distances, S[N*N] = Q + Q^T, r[N], stats[8] = {w1, w2, 1/sum(W), a, b, V, 0, 0}.
+// M[y][x] = (x > y) ? (same ? w1 : -w2) : 0 and W[y][x] = (same ? alpha : 1-alpha) / sum are recomputed from the labels
+// wherever they are needed instead of being stored (kLabel2Weight :32-47).
+__global__ __launch_bounds__(256) void k_fisher2_dist(const float* __restrict__ data, float* __restrict__ E, int numD, int N) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= N) return;
+    float dot = 0.f, si = 0.f, sj = 0.f;
+    for (int d = 0; d < numD; d++) {
+        const float xi = data[(size_t)d * N + i], xj = data[(size_t)d * N + j];
+        dot = __fadd_rn(dot, __fmul_rn(xi, xj));
+        si = __fadd_rn(si, __fmul_rn(xi, xi));
+        sj = __fadd_rn(sj, __fmul_rn(xj, xj));
+    }
+    E[(size_t)i * N + j] = __fadd_rn(__fadd_rn(__fmul_rn(-2.0f, dot), sj), si);
+}
+__device__ double block_sum_double(double v, double* sh) {  // blockDim.x == 1024
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(1024) void k_fisher2_stats(const float* __restrict__ labels, const float* __restrict__ E, float* __restrict__ stats,
+                                                        int N, float alpha, double* costOut) {
+    __shared__ double sh[1024];
+    const size_t NN = (size_t)N * N;
+    double triSame = 0, same = 0;
+    for (size_t e = threadIdx.x; e < NN; e += 1024) {
+        const int y = (int)(e / N), x = (int)(e % N);
+        const bool sm = labels[x] == labels[y];
+        if (x > y) triSame += sm ? 1.0 : -1.0;
+        same += sm ? 1.0 : 0.0;
+    }
+    const float diff = (float)block_sum_double(triSame, sh);
+    const double nSame = block_sum_double(same, sh);
+    const float n = N * (N - 1.0f) / 2.0f;
+    const float w1 = 2.0f / (n + diff), w2 = 2.0f / (n - diff);
+    const float wsum = (float)(nSame * (double)alpha + ((double)NN - nSame) * (double)(1.0f - alpha));
+    const float inv = 1.0f / wsum;
+    double a = 0, b = 0;
+    for (size_t e = threadIdx.x; e < NN; e += 1024) {
+        const int y = (int)(e / N), x = (int)(e % N);
+        const bool sm = labels[x] == labels[y];
+        const float m = x > y ? (sm ? w1 : -w2) : 0.f, w = __fmul_rn(sm ? alpha : 1.0f - alpha, inv);
+        a += (double)__fmul_rn(m, E[e]);
+        b += (double)__fmul_rn(E[e], w);
+    }
+    const float fa = (float)block_sum_double(a, sh), fb = (float)block_sum_double(b, sh);
+    double V = 0;
+    for (size_t e = threadIdx.x; e < NN; e += 1024) {
+        const int y = (int)(e / N), x = (int)(e % N);
+        const float w = __fmul_rn(labels[x] == labels[y] ? alpha : 1.0f - alpha, inv);
+        const float c = __fadd_rn(E[e], -fb);
+        V += (double)__fmul_rn(__fmul_rn(c, c), w);
+    }
+    const float fV = (float)block_sum_double(V, sh);
+    if (threadIdx.x == 0) {
+        stats[0] = w1; stats[1] = w2; stats[2] = inv; stats[3] = fa; stats[4] = fb; stats[5] = fV; stats[6] = 0.f; stats[7] = 0.f;
+        if (costOut) *costOut += (double)(__fmul_rn(-fa, fa) / fV * (float)N);  // layer.cu:1031-1034: cost * numCases
+    }
+}
+// block i: S[i][:] = Q[i][:] + Q[:][i] with Q = -4a M + 4a^2 (E.W) - 4a^2 b W (:439-440), a = a / V (:436), and
+// r[i] = the two tm vectors of :443-450 / :460-464 for index i, added
+__global__ __launch_bounds__(256) void k_fisher2_q(const float* __restrict__ labels, const float* __restrict__ E, const float* __restrict__ stats,
+                                                   float* __restrict__ S, float* __restrict__ r, int N, float alpha) {
+    __shared__ double sh[6][256];
+    const int i = blockIdx.x;
+    const float w1 = stats[0], w2 = stats[1], inv = stats[2], b = stats[4];
+    const float a = stats[3] / stats[5];
+    const float c1 = -4.0f * a, c2 = 4.0f * a * a, c3 = -4.0f * a * a * b;
+    const float li = labels[i];
+    double rs[6] = {0, 0, 0, 0, 0, 0};  // row sums of M, EW, W; column sums of M, EW, W
+    for (int k = threadIdx.x; k < N; k += 256) {
+        const bool sm = labels[k] == li;
+        const float w = __fmul_rn(sm ? alpha : 1.0f - alpha, inv);
+        const float mRow = k > i ? (sm ? w1 : -w2) : 0.f, mCol = i > k ? (sm ? w1 : -w2) : 0.f;  // M[i][k], M[k][i]
+        const float ewRow = __fmul_rn(E[(size_t)i * N + k], w), ewCol = __fmul_rn(E[(size_t)k * N + i], w);
+        const float qRow = __fadd_rn(__fadd_rn(__fmul_rn(c1, mRow), __fmul_rn(c2, ewRow)), __fmul_rn(c3, w));
+        const float qCol = __fadd_rn(__fadd_rn(__fmul_rn(c1, mCol), __fmul_rn(c2, ewCol)), __fmul_rn(c3, w));
+        S[(size_t)i * N + k] = __fadd_rn(qRow, qCol);
+        rs[0] += mRow; rs[1] += ewRow; rs[2] += w; rs[3] += mCol; rs[4] += ewCol; rs[5] += w;
+    }
+    for (int q = 0; q < 6; q++) sh[q][threadIdx.x] = rs[q];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int q = 0; q < 6; q++) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float d1 = 4.0f * a, d2 = -4.0f * a * a, d3 = 4.0f * a * a * b;
+        const float tr = __fadd_rn(__fadd_rn(__fmul_rn(d1, (float)sh[0][0]), __fmul_rn(d2, (float)sh[1][0])), __fmul_rn(d3, (float)sh[2][0]));
+        const float tc = __fadd_rn(__fadd_rn(__fmul_rn(d1, (float)sh[3][0]), __fmul_rn(d2, (float)sh[4][0])), __fmul_rn(d3, (float)sh[5][0]));
+        r[i] = __fadd_rn(tr, tc);
+    }
+}
+// target[d][n] (+)= coeff * (x[d][n] r[n] + sum_k x[d][k] S[k][n])   (S is symmetric: read along n)
+__global__ __launch_bounds__(256) void k_fisher2_grad(const float* __restrict__ data, const float* __restrict__ S, const float* __restrict__ r,
+                                                      float* __restrict__ target, int numD, int N, int add, float coeff) {
+    const int n = blockIdx.x * 256 + threadIdx.x, d = blockIdx.y;
+    if (n >= N) return;
+    const float* x = data + (size_t)d * N;
+    float p = 0.f;
+    for (int k = 0; k < N; k++) p = fmaf(x[k], S[(size_t)k * N + n], p);
+    const float g = (x[n] * r[n] + p) * coeff;
+    float* t = target + (size_t)d * N + n;
+    *t = add ? *t + g : g;
+}
+MCN_API size_t mcn_fisher2_workspace_bytes(int numCases) { return ((size_t)2 * numCases * numCases + numCases + 8) * sizeof(float); }
+static int fisher2_common(const float* labels, const float* data, int numD, int N, float alpha, double* costOut, float* ws, size_t wsBytes,
+                          hipStream_t s) {
+    MCN_REQUIRE(labels && data && numD > 0 && N > 1, "fisher2: bad argument");
+    MCN_REQUIRE(N <= 65535, "fisher2: too many cases");
+    const size_t need = mcn_fisher2_workspace_bytes(N);
+    if (!ws || wsBytes < need) {
+        mcn_set_error("fisher2: workspace %zu < %zu bytes", wsBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    float* E = ws;
+    float* stats = ws + (size_t)2 * N * N + N;
+    hipLaunchKernelGGL(k_fisher2_dist, dim3(divup(N, 256), N), dim3(256), 0, s, data, E, numD, N);
+    hipLaunchKernelGGL(k_fisher2_stats, dim3(1), dim3(1024), 0, s, labels, (const float*)E, stats, N, alpha, costOut);
+    return MCN_LAUNCH_CHECK("fisher2");
+}
+MCN_API int mcn_fisher2_cost(const float* labels, const float* data, int numD, int numCases, float alpha, double* costOut,
+                             void* workspace, size_t workspaceBytes, void* stream) {
+    return fisher2_common(labels, data, numD, numCases, alpha, costOut, (float*)workspace, workspaceBytes, (hipStream_t)stream);
+}
+MCN_API int mcn_fisher2_grad(const float* labels, const float* data, float* target, int numD, int numCases, float alpha, int add,
+                             float coeff, void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(target, "fisher2Grad: null target");
+    hipStream_t s = (hipStream_t)stream;
+    const int rc = fisher2_common(labels, data, numD, numCases, alpha, nullptr, (float*)workspace, workspaceBytes, s);
+    if (rc != MCN_OK) return rc;
+    const int N = numCases;
+    float* E = (float*)workspace;
+    float* S = E + (size_t)N * N;
+    float* r = S + (size_t)N * N;
+    float* stats = r + N;
+    hipLaunchKernelGGL(k_fisher2_q, dim3(N), dim3(256), 0, s, labels, (const float*)E, (const float*)stats, S, r, N, alpha);
+    hipLaunchKernelGGL(k_fisher2_grad, dim3(divup(N, 256), numD), dim3(256), 0, s, data, (const float*)S, (const float*)r, target, numD, N, add,
+                       coeff);
+    return MCN_LAUNCH_CHECK("fisher2Grad");
+}

@@ -686,6 +686,26 @@ void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  //
                                  _info.p, scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2sn grad");
 }
 
+Fisher2CostLayer::Fisher2CostLayer(ConvNet* net, const Params& p) : CostLayer(net, p) { _alpha = (float)pfloat(p, "alpha"); }  // layer.cu:1020-1023
+
+size_t Fisher2CostLayer::workspaceBytes(int maxCases) { return mcn_fisher2_workspace_bytes(maxCases); }
+
+void Fisher2CostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1025-1036
+    if (i != 0) return;
+    if (_net->dataParallel()) throw NetError("cost.fisher2 couples every pair of the minibatch: not defined for data-parallel replicas");
+    float *labels = _inputs[0], *data = _inputs[1];
+    _net->deferSideWork([this, labels, data] {  // the value is read by nothing downstream
+        chk(mcn_fisher2_cost(labels, data, _prev[1]->outputs(), _net->numCases(), _alpha, dCost, _net->workspace(), _net->workspaceBytes(),
+                             _net->stream()), "fisher2 cost");
+    }, 0);
+}
+
+void Fisher2CostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1038-1047
+    if (i != 1) return;
+    chk(mcn_fisher2_grad(_prev[0]->getActs(), _prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(), _alpha,
+                         scaleTargets == 1 ? 1 : 0, _coeff, _net->workspace(), _net->workspaceBytes(), _net->stream()), "fisher2 grad");
+}
+
 void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
     if (i != 0) return;
     float *ground = _inputs[0], *pred = _inputs[1];
@@ -789,6 +809,7 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
         else if (t == "cost.logreg") { auto* c = new LogregCostLayer(this, p); _costs.push_back(c); l = c; }
         else if (t == "cost.sum2") { auto* c = new SumOfSquaresCostLayer(this, p); _costs.push_back(c); l = c; }
         else if (t == "cost.l2-sn") { auto* c = new L2SNCostLayer(this, p); _costs.push_back(c); l = c; }
+        else if (t == "cost.fisher2") { auto* c = new Fisher2CostLayer(this, p); _costs.push_back(c); l = c; }
         else if (t == "cost.l2-reg") { auto* c = new L2regCostLayer(this, p); _costs.push_back(c); l = c; }
         else throw NetError("Unknown layer type " + t);
         _layers.emplace_back(l);

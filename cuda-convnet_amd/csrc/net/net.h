@@ -326,6 +326,17 @@ class L2SNCostLayer : public CostLayer {
     int _extCount = 0;
 };
 
+class Fisher2CostLayer : public CostLayer {  // layer.cu:1017-1047
+   public:
+    Fisher2CostLayer(ConvNet* net, const Params& p);
+    size_t actsElems(int) const override { return 4; }
+    size_t workspaceBytes(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    float _alpha;
+};
+
 class L2regCostLayer : public CostLayer {
    public:
     using CostLayer::CostLayer;

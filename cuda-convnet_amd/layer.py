@@ -40,7 +40,7 @@ NEURONS = OrderedDict([
     ('tanh', (('a', 'b'), True, False)),
 ])
 
-UNSUPPORTED = ('cnorm', 'nailbed', 'blur', 'resize', 'rgb2yuv', 'rgb2lab', 'rscale', 'shift', 'cost.fisher2')
+UNSUPPORTED = ('cnorm', 'nailbed', 'blur', 'resize', 'rgb2yuv', 'rgb2lab', 'rscale', 'shift')
 
 
 def parse_neuron(name, s):
@@ -384,7 +384,7 @@ def _parse_cost(name, cfg, prev, ctx, num_inputs):
     dic['requiresParams'] = True
     del dic['neuron']
     t = dic['type']
-    if t in ('cost.logreg', 'cost.l2-sn'):
+    if t in ('cost.logreg', 'cost.l2-sn', 'cost.fisher2'):
         _check(dic['numInputs'][0] == 1, "Layer '%s': dimensionality of first input must be 1" % name)
     if t == 'cost.logreg':
         _check(prev[dic['inputs'][1]]['type'] == 'softmax', "Layer '%s': second input must be softmax layer" % name)
@@ -394,6 +394,8 @@ def _parse_cost(name, cfg, prev, ctx, num_inputs):
                    % (name, prev[dic['inputs'][1]]['name'], ctx.num_classes))
     if t == 'cost.l2-sn':
         dic['m'] = cfg.get_float(name, 'm')
+    if t == 'cost.fisher2':  # Fisher2CostParser layer.py:1110-1122
+        dic['alpha'] = cfg.get_float(name, 'alpha')
     return dic
 
 
@@ -413,6 +415,7 @@ PARSERS = {
     'cost.sum2': lambda n, c, p, x: _parse_cost(n, c, p, x, 1),
     'cost.l2-sn': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
     'cost.l2-reg': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
+    'cost.fisher2': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
 }
 
 

@@ -257,6 +257,14 @@ int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int numD, int
                              const float* info, int add, float coeff, void* stream);
 /* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2] */
 int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream);
+/* computeFisher2Cost / computeFisher2Grad (layer_kernels.cu:310-369, :371-479; kLabel2Weight :32-47).
+ * costOut (device double, may be NULL) += cost * numCases (Fisher2CostLayer::fpropActs layer.cu:1025-1036);
+ * dataTarget (numD, numCases) (+)= coeff * gradient.  workspace: mcn_fisher2_workspace_bytes(numCases). */
+size_t mcn_fisher2_workspace_bytes(int numCases);
+int mcn_fisher2_cost(const float* labels, const float* data, int numD, int numCases, float alpha, double* costOut,
+                     void* workspace, size_t workspaceBytes, void* stream);
+int mcn_fisher2_grad(const float* labels, const float* data, float* dataTarget, int numD, int numCases, float alpha, int add,
+                     float coeff, void* workspace, size_t workspaceBytes, void* stream);
 /* computeL2regCost / computeL2regGrad (layer_kernels.cu:744-794) */
 int mcn_l2reg_cost(const float* ground, const float* data, float* output, int numD, int numCases,
                    double* costOut, void* stream);

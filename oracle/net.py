@@ -470,6 +470,22 @@ class L2SNCostLayer(CostLayer):
                         target=self.prev[1].get_acts_grad(), add=st == 1)
 
 
+class Fisher2CostLayer(CostLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:1025-1036
+        if i == 0:
+            if self.net.comm is not None:
+                raise ValueError('cost.fisher2 couples every pair of the minibatch: not defined for data-parallel replicas')
+            labels, data = self.inputs
+            n = self.net.num_cases
+            self.costv = [float(np.float32(K.fisher2_cost(labels, data, data.shape[0], n, self.d['alpha'])) * np.float32(n))]
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:1038-1047
+        if i == 1:
+            data = self.prev[1].acts
+            K.fisher2_grad(self.prev[0].acts, data, data.shape[0], self.net.num_cases, self.d['alpha'], self.coeff,
+                           target=self.prev[1].get_acts_grad(), add=st == 1)
+
+
 class L2regCostLayer(CostLayer):
     def fprop_acts(self, i, st, pt):  # layer.cu:1093-1105
         if i == 0:
@@ -489,7 +505,7 @@ _TYPES = {'fc': FCLayer, 'conv': ConvLayer, 'local': LocalUnsharedLayer, 'pool':
           'rnorm': ResponseNormLayer, 'cmrnorm': CrossMapResponseNormLayer, 'softmax': SoftmaxLayer,
           'eltsum': EltwiseSumLayer, 'eltmax': EltwiseMaxLayer, 'neuron': NeuronLayer, 'data': DataLayer,
           'cost.logreg': LogregCostLayer, 'cost.sum2': SumOfSquaresCostLayer, 'cost.l2-sn': L2SNCostLayer,
-          'cost.l2-reg': L2regCostLayer}
+          'cost.l2-reg': L2regCostLayer, 'cost.fisher2': Fisher2CostLayer}
 
 
 class OracleNet:

@@ -261,3 +261,17 @@ def l2reg_grad(ground, data, D, N, coeff, target=None, add=False):
 def sgd_update(W, inc, grad, mom, wc, eps, use_grad):
     lib().orc_sgd_update(_p(W), _p(inc), _p(grad) if grad is not None else None, C.c_size_t(W.size),
                          _f(mom), _f(wc), _f(eps), int(use_grad))
+
+
+def fisher2_cost(labels, data, D, N, alpha):
+    """computeFisher2Cost (layer_kernels.cu:310-369) -> the scalar the layer multiplies by numCases (layer.cu:1031-1034)."""
+    lib().orc_fisher2_cost.restype = C.c_float
+    return float(lib().orc_fisher2_cost(_p(_c(labels)), _p(_c(data)), D, N, _f(alpha)))
+
+
+def fisher2_grad(labels, data, D, N, alpha, coeff, target=None, add=False):
+    """computeFisher2Grad (layer_kernels.cu:371-479)."""
+    if target is None:
+        target = np.zeros((D, N), np.float32)
+    lib().orc_fisher2_grad(_p(_c(labels)), _p(_c(data)), _p(target), D, N, _f(alpha), int(add), _f(coeff))
+    return target

@@ -709,3 +709,29 @@ def test_tile_minibatches(rows, cases, mb):
     for i in range(0, cases, mb):
         n = min(mb, cases - i)
         assert np.array_equal(got[i * rows:i * rows + rows * n].reshape(rows, n), src[:, i:i + n])
+
+
+@pytest.mark.parametrize('D,N,classes', [(160, 128, 40), (12, 16, 4), (33, 50, 7), (160, 128, 10575)])
+def test_fisher2(D, N, classes):
+    """cost.fisher2 (layer_kernels.cu:310-479) against the step-by-step CPU restatement."""
+    rng = np.random.default_rng(41)
+    data = mk(rng, D, N, scale=0.3)
+    labels = rng.integers(0, classes, N).astype(np.float32).reshape(1, N)
+    if classes > N:  # nearly all identities distinct: make sure some pairs match
+        labels[0, N // 2:N // 2 + 8] = labels[0, :8]
+    alpha = 0.3
+    want = O.fisher2_cost(labels, data, D, N, alpha)
+    nbytes = call('mcn_fisher2_workspace_bytes', N)
+    ws = dev_empty((nbytes // 4,), np.nan)
+    d_cost = dev_double(1)
+    call('mcn_fisher2_cost', dev(labels), dev(data), D, N, alpha, d_cost, ws, nbytes, None)
+    got = d_cost.numpy()[0]
+    assert abs(got - want * N) <= 1e-4 * abs(want * N) + 1e-9, (got, want * N)
+    for add in (0, 1):
+        t0 = mk(rng, D, N, scale=0.01)
+        wg = O.fisher2_grad(labels, data, D, N, alpha, 0.5, target=t0.copy(), add=bool(add))
+        d_t = dev(t0)
+        call('mcn_fisher2_grad', dev(labels), dev(data), d_t, D, N, alpha, add, 0.5, ws, nbytes, None)
+        close(d_t.numpy(), wg, rtol=1e-4, atol=1e-7, what='fisher2 grad')
+    with pytest.raises(Exception):
+        call('mcn_fisher2_cost', dev(labels), dev(data), D, N, alpha, d_cost, ws, 16, None)

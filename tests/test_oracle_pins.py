@@ -114,3 +114,53 @@ def test_first_batch_costs_match_reference_logs():
         costs, n = OracleNet(copy.deepcopy(L), 128).run_batch(dp.get_next_batch()[2], test=True)
         assert abs(costs['logprob'][0] / n - math.log(K)) < 0.02 * math.log(K)
         assert costs['logprob'][1] / n >= 0.98
+
+
+def test_fisher2_cost_and_gradient_are_consistent():
+    """cost.fisher2 has no golden vector in the reference (parity unpinned).  Soft pins: the step-by-step C restatement of
+    layer_kernels.cu:310-479 equals an independent float64 formula -a^2/V, its gradient is -dC/dX by central differences
+    (the whole net back-propagates -dE/dx), and the value is a small negative number like the reference's own log
+    (deepidn/nohup.out:69-75: fisher -0.04 ... -0.39 on the first batches)."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    D, N, alpha = 12, 16, 0.5
+    X = (rng.standard_normal((D, N)) * 0.5).astype(np.float32)
+    lab = rng.integers(0, 4, N).astype(np.float32).reshape(1, N)
+
+    def cost64(Xd):
+        l = lab.reshape(-1)
+        same = l[None, :] == l[:, None]
+        tri = np.triu(np.ones((N, N), bool), 1)
+        diff = (np.where(same, 1, -1) * tri).sum()
+        n = N * (N - 1) / 2
+        M = np.where(same, 2 / (n + diff), -2 / (n - diff)) * tri
+        W = np.where(same, alpha, 1 - alpha)
+        W = W / W.sum()
+        s = (Xd * Xd).sum(0)
+        E = s[None, :] + s[:, None] - 2 * Xd.T @ Xd
+        a, b = (M * E).sum(), (W * E).sum()
+        return -a * a / (W * (E - b) ** 2).sum()
+
+    c = O.fisher2_cost(lab, X, D, N, alpha)
+    assert abs(c - cost64(X.astype(np.float64))) < 1e-5 * abs(c)
+    assert -1.0 < c < 0.0
+    g = O.fisher2_grad(lab, X, D, N, alpha, 1.0)
+    num = np.zeros((D, N))
+    h = 1e-5
+    for d in range(D):
+        for n in range(N):
+            Xp, Xm = X.astype(np.float64), X.astype(np.float64)
+            Xp[d, n] += h
+            Xm[d, n] -= h
+            num[d, n] = (cost64(Xp) - cost64(Xm)) / (2 * h)
+    assert np.abs(g + num).max() < 1e-4 * np.abs(num).max()
+    # add / coeff semantics of computeFisher2Grad (:471-478)
+    t0 = rng.standard_normal((D, N)).astype(np.float32)
+    g2 = O.fisher2_grad(lab, X, D, N, alpha, 0.25, target=t0.copy(), add=True)
+    assert np.allclose(g2, t0 + 0.25 * g, rtol=1e-5, atol=1e-7)
+
+
+def test_deepidn_preset_parses_with_fisher2():
+    _, L = parse('deepidn')
+    f = [l for l in L if l['type'] == 'cost.fisher2']
+    assert len(f) == 1 and f[0]['alpha'] == 0.5 and f[0]['coeff'] == 1 and f[0]['numInputs'][0] == 1
