@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_pool_undo(const float* __restrict__ img
 
 // CROSS = false: window over pixels of the same map; true: over neighbouring maps
 template <int VW, bool CROSS>
-__global__ __launch_bounds__(256) void k_rnorm(const float* __restrict__ imgs, float* __restrict__ denoms,
+__global__ __launch_bounds__(256) void k_rnorm(const float* __restrict__ imgs, const float* __restrict__ md, float* __restrict__ denoms,
                                                float* __restrict__ target, int numImages, int numFilters, int imgY,
                                                int imgX, int size, float addScale, float powScale, int blocked) {
     const int imgPixels = imgY * imgX;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_rnorm(const float* __restrict__ imgs, f
         const int startF = blocked ? (f / size) * size : -size / 2 + f;
         const int f0 = blocked ? startF : max(0, startF), f1 = min(numFilters, startF + size);
         for (int ff = f0; ff < f1; ff++) {
-            const Vec<VW> s = Vec<VW>::load(imgs + ((size_t)ff * imgPixels + px) * numImages + n);
+            const Vec<VW> s = Vec<VW>::load(md + ((size_t)ff * imgPixels + px) * numImages + n);
             acc.v += s.v * s.v;
         }
     } else {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_rnorm(const float* __restrict__ imgs, f
         const int y1 = min(imgY, y - size / 2 + size), x1 = min(imgX, x - size / 2 + size);
         for (int yy = y0; yy < y1; yy++)
             for (int xx = x0; xx < x1; xx++) {
-                const Vec<VW> s = Vec<VW>::load(imgs + ((size_t)f * imgPixels + yy * imgX + xx) * numImages + n);
+                const Vec<VW> s = Vec<VW>::load(md + ((size_t)f * imgPixels + yy * imgX + xx) * numImages + n);
                 acc.v += s.v * s.v;
             }
     }
@@ -269,16 +269,18 @@ MCN_API int mcn_local_avg_undo(const float* avgGrads, float* target, int numImag
                           strideX, outputsY, outputsX, scaleTargets, scaleOutput, 1, -1, 0.f, 0.f, stream);
 }
 
-static int rnorm_impl(const float* images, float* denoms, float* target, int numImages, int numFilters, int imgY,
+// md: what the window squares and sums -- the images themselves (response norm) or images minus their local mean
+// (contrast norm, conv_util.cu:2064-2066 vs :2074)
+static int rnorm_impl(const float* images, const float* md, float* denoms, float* target, int numImages, int numFilters, int imgY,
                       int imgX, int size, float addScale, float powScale, int blocked, bool cross, void* stream) {
-    MCN_REQUIRE(images && denoms && target, "responseNorm: null pointer");
+    MCN_REQUIRE(images && md && denoms && target, "responseNorm: null pointer");
     MCN_REQUIRE(numImages > 0 && numFilters > 0 && imgY > 0 && imgX > 0 && size > 0, "responseNorm: non-positive dimension");
     MCN_REQUIRE(!cross || (size <= numFilters && numFilters % 16 == 0), "responseNormCrossMap: need sizeF <= numFilters, numFilters %% 16 == 0");
     const long long rows = (long long)numFilters * imgY * imgX;
     hipStream_t s = (hipStream_t)stream;
-    const bool v4 = vec_ok(numImages, {images, denoms, target});
+    const bool v4 = vec_ok(numImages, {images, md, denoms, target});
     dim3 grid(blocks_for(rows, numImages, v4 ? 4 : 1));
-#define RN_ARGS images, denoms, target, numImages, numFilters, imgY, imgX, size, addScale, powScale, blocked
+#define RN_ARGS images, md, denoms, target, numImages, numFilters, imgY, imgX, size, addScale, powScale, blocked
     if (cross) {
         if (v4) hipLaunchKernelGGL((k_rnorm<4, true>), grid, dim3(256), 0, s, RN_ARGS);
         else hipLaunchKernelGGL((k_rnorm<1, true>), grid, dim3(256), 0, s, RN_ARGS);
@@ -317,7 +319,12 @@ static int rnorm_undo_impl(const float* outGrads, const float* denoms, const flo
 
 MCN_API int mcn_response_norm(const float* images, float* denoms, float* target, int numImages, int numFilters,
                               int imgSizeY, int imgSizeX, int sizeX, float addScale, float powScale, void* stream) {
-    return rnorm_impl(images, denoms, target, numImages, numFilters, imgSizeY, imgSizeX, sizeX, addScale, powScale, 0, false, stream);
+    return rnorm_impl(images, images, denoms, target, numImages, numFilters, imgSizeY, imgSizeX, sizeX, addScale, powScale, 0, false, stream);
+}
+
+MCN_API int mcn_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target, int numImages, int numFilters,
+                              int imgSizeY, int imgSizeX, int sizeX, float addScale, float powScale, void* stream) {
+    return rnorm_impl(images, meanDiffs, denoms, target, numImages, numFilters, imgSizeY, imgSizeX, sizeX, addScale, powScale, 0, false, stream);
 }
 
 MCN_API int mcn_response_norm_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,
@@ -330,7 +337,7 @@ MCN_API int mcn_response_norm_undo(const float* outGrads, const float* denoms, c
 MCN_API int mcn_response_norm_cross_map(const float* images, float* denoms, float* target, int numImages,
                                         int numFilters, int imgPixels, int sizeF, float addScale, float powScale,
                                         int blocked, void* stream) {
-    return rnorm_impl(images, denoms, target, numImages, numFilters, 1, imgPixels, sizeF, addScale, powScale, blocked, true, stream);
+    return rnorm_impl(images, images, denoms, target, numImages, numFilters, 1, imgPixels, sizeF, addScale, powScale, blocked, true, stream);
 }
 
 MCN_API int mcn_response_norm_cross_map_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,

@@ -596,6 +596,28 @@ void ResponseNormLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
                                    _size, _scale, _pow, scaleTargets, 1.f, _net->stream()), "rnorm undo");
 }
 
+// ============================================================================ ContrastNormLayer (layer.cu:893-913)
+void ContrastNormLayer::allocate(int maxCases) {
+    ResponseNormLayer::allocate(maxCases);
+    _meanDiffs.ensure((size_t)_outputs * maxCases);
+}
+
+void ContrastNormLayer::fpropActs(int, float, PassType) {  // layer.cu:897-902
+    const int n = _net->numCases();
+    // local mean over the (clipped) size x size window around every pixel, then images - mean
+    chk(mcn_local_pool(_inputs[0], _meanDiffs.p, n, _channels, _imgSizeY, _imgSizeX, _size, -_size / 2, 1, _imgSizeY, _imgSizeX, 1,
+                       _net->stream()), "cnorm mean");
+    chk(mcn_axpby(_meanDiffs.p, _inputs[0], (size_t)_outputs * n, -1.f, 1.f, _net->stream()), "cnorm mean diffs");
+    chk(mcn_contrast_norm(_inputs[0], _meanDiffs.p, _denoms.p, _acts, n, _channels, _imgSizeY, _imgSizeX, _size, _scale, _pow,
+                          _net->stream()), "cnorm");
+}
+
+void ContrastNormLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // layer.cu:904-906; destroys own acts
+    _net->joinGradWork();
+    chk(mcn_response_norm_undo(v, _denoms.p, _meanDiffs.p, _acts, _prev[0]->getActsGrad(), _net->numCases(), _channels, _imgSizeY,
+                               _imgSizeX, _size, _scale, _pow, scaleTargets, 1.f, _net->stream()), "cnorm undo");
+}
+
 // ============================================================================ Cost layers (layer.cu:920-1116)
 CostLayer::CostLayer(ConvNet* net, const Params& p) : Layer(net, p) { _coeff = (float)pfloat(p, "coeff"); }
 
@@ -801,6 +823,7 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
         else if (t == "pool") l = new PoolLayer(this, p);
         else if (t == "rnorm") l = new ResponseNormLayer(this, p, false);
         else if (t == "cmrnorm") l = new ResponseNormLayer(this, p, true);
+        else if (t == "cnorm") l = new ContrastNormLayer(this, p);
         else if (t == "softmax") l = new SoftmaxLayer(this, p);
         else if (t == "eltsum") l = new EltwiseSumLayer(this, p);
         else if (t == "eltmax") l = new EltwiseMaxLayer(this, p);

@@ -276,6 +276,16 @@ class ResponseNormLayer : public Layer {
     DBuf _denoms;
 };
 
+class ContrastNormLayer : public ResponseNormLayer {  // layer.cu:893-913
+   public:
+    ContrastNormLayer(ConvNet* net, const Params& p) : ResponseNormLayer(net, p, false) {}
+    void allocate(int maxCases) override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    DBuf _meanDiffs;
+};
+
 class CostLayer : public Layer {
    public:
     CostLayer(ConvNet* net, const Params& p);

@@ -40,7 +40,7 @@ NEURONS = OrderedDict([
     ('tanh', (('a', 'b'), True, False)),
 ])
 
-UNSUPPORTED = ('cnorm', 'nailbed', 'blur', 'resize', 'rgb2yuv', 'rgb2lab', 'rscale', 'shift')
+UNSUPPORTED = ('nailbed', 'blur', 'resize', 'rgb2yuv', 'rgb2lab', 'rscale', 'shift')
 
 
 def parse_neuron(name, s):
@@ -411,6 +411,7 @@ PARSERS = {
     'pool': _parse_pool,
     'rnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, False),
     'cmrnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, True),
+    'cnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, False),
     'cost.logreg': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
     'cost.sum2': lambda n, c, p, x: _parse_cost(n, c, p, x, 1),
     'cost.l2-sn': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
@@ -484,7 +485,7 @@ def _add_params(dic, pcfg):
         for k in ('epsW', 'momW', 'wc'):
             _check(len(dic[k]) == len(dic['inputs']), "Layer '%s': %s list length does not match number of inputs" % (name, k))
         dic['gradConsumer'] = dic['epsB'] > 0 or any(w > 0 for w in dic['epsW'])
-    elif t in ('rnorm', 'cmrnorm'):
+    elif t in ('rnorm', 'cmrnorm', 'cnorm'):
         dic['scale'] = pcfg.get_float(name, 'scale')
         dic['scale'] /= dic['size'] if t == 'cmrnorm' else dic['size'] ** 2
         dic['pow'] = pcfg.get_float(name, 'pow')

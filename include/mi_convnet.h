@@ -166,6 +166,11 @@ int mcn_local_avg_undo(const float* avgGrads, float* target, int numImages, int 
 /* convResponseNorm (conv_util.cuh:43, conv_util.cu:2064-2072) */
 int mcn_response_norm(const float* images, float* denoms, float* target, int numImages, int numFilters,
                       int imgSizeY, int imgSizeX, int sizeX, float addScale, float powScale, void* stream);
+/* convContrastNorm (conv_util.cuh:46-47, conv_util.cu:2074-2160): denoms = 1 + addScale * window sum of meanDiffs^2,
+ * target = images * denoms^-powScale.  Its gradient convContrastNormUndo (conv_util.cu:2214-2217) is
+ * mcn_response_norm_undo with inputs = meanDiffs. */
+int mcn_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target, int numImages,
+                      int numFilters, int imgSizeY, int imgSizeX, int sizeX, float addScale, float powScale, void* stream);
 /* convResponseNormUndo (conv_util.cuh:44-45, conv_util.cu:2228-2412). OVERWRITES acts. */
 int mcn_response_norm_undo(const float* outGrads, const float* denoms, const float* inputs, float* acts,
                            float* target, int numImages, int numFilters, int imgSizeY, int imgSizeX, int sizeX,

@@ -288,7 +288,9 @@ ORC void orc_local_avg_undo(const float* avgGrads, float* target, int numImages,
 // with meanDiffs == images, host convResponseNorm :2064-2072):
 //   denom = 1 + addScale * sum_{window} x^2 ; y = x * denom^-pow
 // ---------------------------------------------------------------------------
-ORC void orc_response_norm(const float* images, float* denoms, float* target, int numImages,
+// convContrastNorm (conv_util.cu:2074-2160; kCNorm* :790-1000): the window sums squares of meanDiffs, the output
+// scales images.  convResponseNorm (:2064-2066) is the same call with meanDiffs = images.
+ORC void orc_contrast_norm(const float* images, const float* meanDiffs, float* denoms, float* target, int numImages,
                            int numFilters, int imgSizeY, int imgSizeX, int sizeX,
                            float addScale, float powScale) {
     const int imgPixels = imgSizeY * imgSizeX;
@@ -304,7 +306,7 @@ ORC void orc_response_norm(const float* images, float* denoms, float* target, in
                 std::fill(acc.begin(), acc.end(), 0.f);
                 for (int yy = y0; yy < y1; yy++)
                     for (int xx = x0; xx < x1; xx++) {
-                        const float* s = images + ((size_t)f * imgPixels + yy * imgSizeX + xx) * numImages;
+                        const float* s = meanDiffs + ((size_t)f * imgPixels + yy * imgSizeX + xx) * numImages;
                         for (int n = 0; n < numImages; n++) acc[n] += s[n] * s[n];
                     }
                 const size_t o = ((size_t)f * imgPixels + px) * numImages;
@@ -316,6 +318,12 @@ ORC void orc_response_norm(const float* images, float* denoms, float* target, in
             }
         }
     }
+}
+
+ORC void orc_response_norm(const float* images, float* denoms, float* target, int numImages,
+                           int numFilters, int imgSizeY, int imgSizeX, int sizeX,
+                           float addScale, float powScale) {
+    orc_contrast_norm(images, images, denoms, target, numImages, numFilters, imgSizeY, imgSizeX, sizeX, addScale, powScale);
 }
 
 // convResponseNormUndo (conv_util.cu:1592-1605 prelims, :1629-1712 main, host

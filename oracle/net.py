@@ -408,6 +408,23 @@ class CrossMapResponseNormLayer(ResponseNormLayer):
     cross = True
 
 
+class ContrastNormLayer(ResponseNormLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:897-902
+        d, n = self.d, self.net.num_cases
+        x = self.inputs[0]
+        mean = K.local_pool(x, n, d['channels'], d['imgSizeY'], d['imgSizeX'], d['size'], -(d['size'] // 2), 1,
+                            d['imgSizeY'], d['imgSizeX'], 'avg')
+        self.mean_diffs = (np.float32(-1) * mean + np.float32(1) * x).astype(np.float32)  # _meanDiffs.add(images, -1, 1)
+        t, self.denoms = K.contrast_norm(x, self.mean_diffs, n, d['channels'], d['imgSizeY'], d['imgSizeX'], d['size'],
+                                         d['scale'], d['pow'])
+        self.acts[...] = t
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:904-906 (destroys own acts)
+        d, n = self.d, self.net.num_cases
+        K.response_norm_undo(v, self.denoms, self.mean_diffs, self.acts, n, d['channels'], d['imgSizeY'], d['imgSizeX'],
+                             d['size'], d['scale'], d['pow'], target=self.prev[0].get_acts_grad(), sT=float(st), sO=1.0)
+
+
 class CostLayer(Layer):
     def __init__(self, net, d):
         super().__init__(net, d)
@@ -502,7 +519,7 @@ class L2regCostLayer(CostLayer):
 
 
 _TYPES = {'fc': FCLayer, 'conv': ConvLayer, 'local': LocalUnsharedLayer, 'pool': PoolLayer,
-          'rnorm': ResponseNormLayer, 'cmrnorm': CrossMapResponseNormLayer, 'softmax': SoftmaxLayer,
+          'rnorm': ResponseNormLayer, 'cmrnorm': CrossMapResponseNormLayer, 'cnorm': ContrastNormLayer, 'softmax': SoftmaxLayer,
           'eltsum': EltwiseSumLayer, 'eltmax': EltwiseMaxLayer, 'neuron': NeuronLayer, 'data': DataLayer,
           'cost.logreg': LogregCostLayer, 'cost.sum2': SumOfSquaresCostLayer, 'cost.l2-sn': L2SNCostLayer,
           'cost.l2-reg': L2regCostLayer, 'cost.fisher2': Fisher2CostLayer}

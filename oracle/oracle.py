@@ -117,6 +117,14 @@ def response_norm(images, N, F, imgY, imgX, size, add_scale, pow_scale):
     return target, denoms
 
 
+def contrast_norm(images, mean_diffs, N, F, imgY, imgX, size, add_scale, pow_scale):
+    """convContrastNorm (conv_util.cu:2074-2160) -> (target, denoms)."""
+    denoms = np.empty_like(images)
+    target = np.empty_like(images)
+    lib().orc_contrast_norm(_p(images), _p(mean_diffs), _p(denoms), _p(target), N, F, imgY, imgX, size, _f(add_scale), _f(pow_scale))
+    return target, denoms
+
+
 def response_norm_undo(out_grads, denoms, inputs, acts, N, F, imgY, imgX, size, add_scale, pow_scale,
                        target=None, sT=0.0, sO=1.0):
     """NOTE: overwrites `acts` like the reference (conv_util.cu:2226)."""

@@ -735,3 +735,28 @@ def test_fisher2(D, N, classes):
         close(d_t.numpy(), wg, rtol=1e-4, atol=1e-7, what='fisher2 grad')
     with pytest.raises(Exception):
         call('mcn_fisher2_cost', dev(labels), dev(data), D, N, alpha, d_cost, ws, 16, None)
+
+
+@pytest.mark.parametrize('F,img,size,N', [(32, 16, 3, 128), (16, 9, 5, 33), (3, 12, 4, 64)])
+def test_contrast_norm(F, img, size, N):
+    """convContrastNorm / convContrastNormUndo (conv_util.cu:2074-2160, :2214-2217) as ContrastNormLayer uses them
+    (layer.cu:897-906): mean over the clipped window, images - mean, normalise, undo with inputs = meanDiffs."""
+    rng = np.random.default_rng(42)
+    x = mk(rng, F * img * img, N, scale=2.0)
+    scale, pw = 0.001 / size ** 2, 0.75
+    mean = O.local_pool(x, N, F, img, img, size, -(size // 2), 1, img, img, 'avg')
+    md = (x - mean).astype(np.float32)
+    want, wden = O.contrast_norm(x, md, N, F, img, img, size, scale, pw)
+    d_mean, d_den, d_out = dev_empty(x.shape, np.nan), dev_empty(x.shape, np.nan), dev_empty(x.shape, np.nan)
+    call('mcn_local_pool', dev(x), d_mean, N, F, img, img, size, -(size // 2), 1, img, img, 1, None)
+    call('mcn_axpby', d_mean, dev(x), x.size, -1.0, 1.0, None)
+    close(d_mean.numpy(), md, what='mean diffs')
+    call('mcn_contrast_norm', dev(x), d_mean, d_den, d_out, N, F, img, img, size, scale, pw, None)
+    close(d_den.numpy(), wden, what='cnorm denoms')
+    close(d_out.numpy(), want, what='cnorm')
+    if F % 16 == 0:  # conv_util.cu:2246
+        g = mk(rng, F * img * img, N)
+        wt = O.response_norm_undo(g, wden, md, want.copy(), N, F, img, img, size, scale, pw)
+        d_t = dev_empty(x.shape, np.nan)
+        call('mcn_response_norm_undo', dev(g), d_den, d_mean, d_out, d_t, N, F, img, img, size, scale, pw, 0.0, 1.0, None)
+        close(d_t.numpy(), wt, what='cnorm undo')

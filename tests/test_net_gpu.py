@@ -89,7 +89,7 @@ def oracle_train(Lc, data, minibatch=128, test=False):
     return net, out
 
 
-@pytest.mark.parametrize('name', ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn'])
+@pytest.mark.parametrize('name', ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm'])
 def test_train_3_steps_matches_oracle(name):
     """C1..C5: three consecutive minibatches of 128 through fprop/bprop/update, then syncWithHost."""
     dp, Lg = preset(name, 384)
