@@ -1,5 +1,6 @@
 // See net.h.  Reference citations are file:line into /root/reference/src unless noted.
 #include "net.h"
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -12,6 +13,21 @@ namespace mcn {
 
 void chk(int rc, const char* what) {
     if (rc != MCN_OK) throw NetError(std::string(what) + ": " + mcn_last_error());
+}
+
+// host time spent in cross-stream synchronisation calls (reported as host.events by runSteps)
+thread_local double g_eventCallMs = 0;
+int timedEventRecord(void* e, void* s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mcn_event_record(e, s);
+    g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+int timedStreamWait(void* s, void* e) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = mcn_stream_wait_event(s, e);
+    g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 DBuf::~DBuf() {
@@ -689,7 +705,7 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
     _extCount = gather ? h * G : 0;
     if (gather) _gathered.ensure((size_t)2 * h * G);
     float *idens = _inputs[0], *data = _inputs[1];
-    _net->forkSideWork([this, idens, data, D, n, h, G, gather] {
+    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather] {
         if (gather) {
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
             _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
@@ -697,13 +713,14 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         }
         chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, gather ? nullptr : _pairStats.p, dCost, gather ? _gathered.p : nullptr,
                           gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
-        chk(mcn_event_record(_evReady, _net->stream()), "event record");
+        chk(timedEventRecord(_evReady, _net->stream()), "event record");
     });
 }
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
-    chk(mcn_stream_wait_event(_net->stream(), _evReady), "wait event");
+    _net->waitSideSubmitted(_readyTicket);  // the side thread has recorded _evReady
+    chk(timedStreamWait(_net->stream(), _evReady), "wait event");
     chk(mcn_l2sn_grad_from_stats(_prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(), _pairStats.p,
                                  _info.p, scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2sn grad");
 }
@@ -855,8 +872,9 @@ ConvNet::~ConvNet() {
     if (_evGrad2) mcn_event_destroy(_evGrad2);
     if (_evGather) mcn_event_destroy(_evGather);
     if (_evComm) mcn_event_destroy(_evComm);
+    stopSideThread();
     if (_gradStream) mcn_stream_destroy(_gradStream);
-    if (_evFork) mcn_event_destroy(_evFork);
+    for (void* e : _forkEvents) mcn_event_destroy(e);
     if (_evJoin) mcn_event_destroy(_evJoin);
     if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
@@ -928,12 +946,13 @@ void ConvNet::run() {  // convnet.cu:147-156
 void ConvNet::initDevice() {  // convnet.cu:139-145
     chk(mcn_set_device(_deviceID < 0 ? 0 : _deviceID), "set device");
     chk(mcn_stream_create(&_stream), "stream");
-    _cur = _stream;
     if (const char* e = getenv("MCN_SIDE_UNITS")) _sideUnits = std::max(1, atoi(e));
     if (getenv("MCN_NO_GRAD_STREAM") == nullptr) {
         chk(mcn_stream_create(&_gradStream), "grad stream");
-        chk(mcn_event_create_sync(&_evFork), "event");
         chk(mcn_event_create_sync(&_evJoin), "event");
+        _forkEvents.resize(32, nullptr);
+        for (void*& e : _forkEvents) chk(mcn_event_create_sync(&e), "event");
+        _sideThread = std::thread([this] { sideLoop(); });
     }
     for (auto& l : _layers) l->copyToGPU();
     buildFusions();
@@ -1022,6 +1041,68 @@ void ConvNet::sync() {
     chk(mcn_stream_sync(_stream), "sync");
 }
 
+// ---- side-stream submission -----------------------------------------------------------------
+static thread_local bool t_sideThread = false;
+
+void* ConvNet::stream() const { return t_sideThread ? _gradStream : _stream; }
+void* ConvNet::workspace() const { return t_sideThread ? _ws2.p : _ws.p; }
+
+void ConvNet::sideLoop() {
+    t_sideThread = true;
+    mcn_set_device(_deviceID < 0 ? 0 : _deviceID);
+    for (;;) {
+        SideTask task;
+        {
+            std::unique_lock<std::mutex> lk(_sideMutex);
+            // work arrives every few tens of microseconds while a step is being submitted: poll before sleeping
+            for (int spin = 0; _sideQueue.empty() && !_sideStop && spin < 20000; spin++) {
+                lk.unlock();
+                std::this_thread::yield();
+                lk.lock();
+            }
+            _sideCv.wait(lk, [this] { return !_sideQueue.empty() || _sideStop; });
+            if (_sideQueue.empty()) return;  // stop requested
+            task = std::move(_sideQueue.front());
+            _sideQueue.pop_front();
+        }
+        try {
+            if (!_sideError) {
+                chk(timedStreamWait(_gradStream, task.forkEvent), "wait event");
+                for (auto& fn : task.fns) fn();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(_sideMutex);
+            if (!_sideError) _sideError = std::current_exception();
+        }
+        _sideDone.fetch_add(1, std::memory_order_release);
+    }
+}
+
+void ConvNet::stopSideThread() {
+    if (!_sideThread.joinable()) return;
+    {
+        std::lock_guard<std::mutex> lk(_sideMutex);
+        _sideStop = true;
+    }
+    _sideCv.notify_all();
+    _sideThread.join();
+}
+
+void ConvNet::checkSideError() {
+    std::exception_ptr e;
+    {
+        std::lock_guard<std::mutex> lk(_sideMutex);
+        std::swap(e, _sideError);
+    }
+    if (e) std::rethrow_exception(e);
+}
+
+void ConvNet::waitSideSubmitted(long ticket) {
+    for (int spin = 0; _sideDone.load(std::memory_order_acquire) < ticket; spin++)
+        if (spin > 64) std::this_thread::yield();
+    checkSideError();
+}
+
 bool ConvNet::lastWeightLayerOfPass() { return ++_wlSeen == _wlPerPass; }
 
 void ConvNet::deferSideWork(std::function<void()> fn, int units, bool hold) {
@@ -1034,35 +1115,37 @@ void ConvNet::deferSideWork(std::function<void()> fn, int units, bool hold) {
     if (!hold && _deferredUnits >= _sideUnits) flushSideWork(_deferred.size());
 }
 
-void ConvNet::forkSideWork(std::function<void()> fn) {
+long ConvNet::forkSideWork(std::function<void()> fn) {
     if (!_gradStream || _profiling) {
         fn();
-        return;
+        return 0;
     }
-    flushSideWork(_deferred.size());  // keeps the order of what was deferred before
     _deferred.emplace_back(std::move(fn), 0);
-    flushSideWork(1);
+    flushSideWork(_deferred.size());  // (together with what was deferred before: keeps the order)
+    return _sidePushed.load(std::memory_order_relaxed);
 }
 
+// the first `count` deferred items become one task of the side thread, ordered after everything the main stream
+// holds at this point
 void ConvNet::flushSideWork(size_t count) {
     if (count == 0) return;
-    chk(mcn_event_record(_evFork, _stream), "event record");
-    chk(mcn_stream_wait_event(_gradStream, _evFork), "wait event");
-    _cur = _gradStream;
-    _gradPending = true;
-    try {
-        for (size_t i = 0; i < count; i++) {
-            _deferred[i].first();
-            _deferredUnits -= _deferred[i].second;
-        }
-    } catch (...) {
-        _cur = _stream;
-        _deferred.clear();
-        _deferredUnits = 0;
-        throw;
+    SideTask task;
+    task.forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
+    // (an event may be recorded again before the side thread has waited for its previous use: that wait then covers
+    // more of the main stream than it needs to, never less; 32 events make it rare)
+    chk(timedEventRecord(task.forkEvent, _stream), "event record");
+    for (size_t i = 0; i < count; i++) {
+        task.fns.push_back(std::move(_deferred[i].first));
+        _deferredUnits -= _deferred[i].second;
     }
-    _cur = _stream;
     _deferred.erase(_deferred.begin(), _deferred.begin() + count);
+    _gradPending = true;
+    {
+        std::lock_guard<std::mutex> lk(_sideMutex);
+        _sideQueue.push_back(std::move(task));
+    }
+    _sidePushed.fetch_add(1, std::memory_order_relaxed);
+    _sideCv.notify_one();
 }
 
 void ConvNet::finishSideWork() {
@@ -1084,8 +1167,9 @@ void ConvNet::joinGradWork() {
         for (auto& d : rest) d.first();  // on the main stream
     }
     if (!_gradPending) return;
-    chk(mcn_event_record(_evJoin, _gradStream), "event record");
-    chk(mcn_stream_wait_event(_stream, _evJoin), "wait event");
+    waitSideSubmitted(_sidePushed.load(std::memory_order_relaxed));  // the side thread has issued everything it was given
+    chk(timedEventRecord(_evJoin, _gradStream), "event record");
+    chk(timedStreamWait(_stream, _evJoin), "wait event");
     _gradPending = false;
 }
 
@@ -1144,12 +1228,22 @@ void ConvNet::copyToCPU() {
 
 // ---- data-parallel gradient exchange ---------------------------------------------------------
 void ConvNet::gradReady(WeightLayer* l) {
-    for (Segment& s : _segments)
-        if (s.layer == l) s.ready = true;
+    {
+        std::lock_guard<std::mutex> lk(_commMutex);
+        for (Segment& s : _segments)
+            if (s.layer == l) {
+                s.ready = true;
+                // which stream(s) hold the kernels that wrote it: the side thread issues both of a layer's pieces on the
+                // side stream; on the main thread the bias piece may have gone to the side stream (last layer of a pass)
+                s.onSide = t_sideThread || _gradPending;
+                s.onMain = !t_sideThread;
+            }
+    }
     flushBuckets(false);
 }
 
 void ConvNet::flushBuckets(bool force) {
+    std::lock_guard<std::mutex> lk(_commMutex);
     // longest run of completed segments starting at the first one not sent yet
     size_t end = _sentUpTo;
     for (Segment& s : _segments) {
@@ -1159,12 +1253,21 @@ void ConvNet::flushBuckets(bool force) {
     }
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
-    // the bucket's gradients were enqueued on the main stream or on the gradient side stream: wait for both
-    chk(mcn_event_record(_evGrad, _stream), "event record");
-    chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
-    if (_gradPending) {
-        chk(mcn_event_record(_evGrad2, _gradStream), "event record");
-        chk(mcn_stream_wait_event(_commStream, _evGrad2), "wait event");
+    // the exchange waits for the stream(s) that hold the kernels writing this bucket (a record + wait pair costs ~16 us
+    // of host time, so only where needed; force: whatever is left, written by either stream)
+    bool onMain = force, onSide = force && _gradPending;
+    for (Segment& sg : _segments)
+        if (sg.end > _sentUpTo && sg.begin < end) {
+            onMain |= sg.onMain;
+            onSide |= sg.onSide;
+        }
+    if (onMain) {
+        chk(timedEventRecord(_evGrad, _stream), "event record");
+        chk(timedStreamWait(_commStream, _evGrad), "wait event");
+    }
+    if (onSide) {
+        chk(timedEventRecord(_evGrad2, _gradStream), "event record");
+        chk(timedStreamWait(_commStream, _evGrad2), "wait event");
     }
     chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
     _sentUpTo = end;
@@ -1172,9 +1275,10 @@ void ConvNet::flushBuckets(bool force) {
 }
 
 void ConvNet::waitComm() {
+    std::lock_guard<std::mutex> lk(_commMutex);
     if (_commPending) {
-        chk(mcn_event_record(_evComm, _commStream), "event record");
-        chk(mcn_stream_wait_event(_stream, _evComm), "wait event");
+        chk(timedEventRecord(_evComm, _commStream), "event record");
+        chk(timedStreamWait(_stream, _evComm), "wait event");
         _commPending = false;
     }
     _sentUpTo = 0;
@@ -1182,18 +1286,19 @@ void ConvNet::waitComm() {
 }
 
 void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
+    std::lock_guard<std::mutex> lk(_commMutex);
     // both gathers in one fused RCCL launch on the exchange stream; consumers call waitGather() when they need the result
-    chk(mcn_event_record(_evGrad, _cur), "event record");
-    chk(mcn_stream_wait_event(_commStream, _evGrad), "wait event");
+    chk(timedEventRecord(_evGrad, stream()), "event record");
+    chk(timedStreamWait(_commStream, _evGrad), "wait event");
     chk(mcn_comm_group_begin(), "group begin");
     chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
     chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
     chk(mcn_comm_group_end(), "group end");
-    chk(mcn_event_record(_evGather, _commStream), "event record");
+    chk(timedEventRecord(_evGather, _commStream), "event record");
 }
 
 void ConvNet::waitGather() {  // on the stream the caller is enqueueing on
-    chk(mcn_stream_wait_event(_cur, _evGather), "wait event");
+    chk(timedStreamWait(stream(), _evGather), "wait event");
 }
 
 // ---- per-operation event timing -----------------------------------------------------------------
@@ -1220,7 +1325,7 @@ void ConvNet::profBegin(const std::string& label) {
         _profLabels.push_back(label);
     }
     ProfSpan s{it->second, profEvent(), nullptr};
-    chk(mcn_event_record(s.e0, _stream), "event record");
+    chk(timedEventRecord(s.e0, _stream), "event record");
     _profSpans.push_back(s);
 }
 
@@ -1229,7 +1334,7 @@ void ConvNet::profEnd() {
     for (size_t i = _profSpans.size(); i-- > 0;)
         if (!_profSpans[i].e1) {
             _profSpans[i].e1 = profEvent();
-            chk(mcn_event_record(_profSpans[i].e1, _stream), "event record");
+            chk(timedEventRecord(_profSpans[i].e1, _stream), "event record");
             return;
         }
 }

@@ -16,6 +16,8 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <exception>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -34,7 +36,10 @@ enum PassType { PASS_TRAIN = 0, PASS_TEST = 1, PASS_GC = 2 };  // util.cuh:43
 struct NetError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
-void chk(int rc, const char* what);  // throws NetError carrying mcn_last_error()
+void chk(int rc, const char* what);
+extern thread_local double g_eventCallMs;
+int timedEventRecord(void* event, void* stream);
+int timedStreamWait(void* stream, void* event);  // throws NetError carrying mcn_last_error()
 
 // growable device float buffer
 class DBuf {
@@ -333,6 +338,7 @@ class L2SNCostLayer : public CostLayer {
     DBuf _pairStats, _info;  // what the cost launch keeps for the gradient: (dists, labels) and {margin, chosen pair, 0, 0}
     DBuf _gathered;          // data-parallel: the all-gathered margin candidates
     void* _evReady = nullptr;  // recorded after the cost launch, on whichever stream ran it
+    long _readyTicket = 0;
     int _extCount = 0;
 };
 
@@ -479,7 +485,7 @@ class ConvNet {
     void runSteps(int numSteps, bool test, int profile);
 
     // ---- services for layers ---------------------------------------------------------------
-    void* stream() const { return _cur; }       // the stream layer operations are issued on right now
+    void* stream() const;                       // the stream layer operations are issued on right now (per submitting thread)
     void* mainStream() const { return _stream; }
     // Weight / bias gradients of a layer depend only on its incoming gradient, so they run on a side stream
     // next to the backward-data chain (joined before the update, before anything overwrites their inputs).
@@ -495,7 +501,7 @@ class ConvNet {
     int worldSize() const { return _world; }
     int rank() const { return _rank; }
     bool dataParallel() const { return _dpOn; }
-    void* workspace() const { return _cur == _gradStream && _gradStream ? _ws2.p : _ws.p; }
+    void* workspace() const;
     size_t workspaceBytes() const { return _ws.cap * sizeof(float); }
     Layer& layer(int i) { return *_layers[i]; }
     int numLayers() const { return (int)_layers.size(); }
@@ -503,7 +509,8 @@ class ConvNet {
     void gradReady(WeightLayer* l);             // data-parallel: layer's gradient segment is complete
     void allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // starts on the exchange stream
     void waitGather();
-    void forkSideWork(std::function<void()> fn);  // starts now, on the side stream
+    long forkSideWork(std::function<void()> fn);  // starts now, on the side stream; returns a ticket for waitSideSubmitted
+    void waitSideSubmitted(long ticket);          // host-side: until the side thread has issued that work
     void setFusion(bool on) { _fusion = on; }
     bool profiling() const { return _profiling; }
     void profBegin(const std::string& label);
@@ -527,11 +534,27 @@ class ConvNet {
     std::vector<float*> _curData;
 
     void* _stream = nullptr;
-    void* _cur = nullptr;
     void* _gradStream = nullptr;  // null: gradients stay on the main stream
-    void* _evFork = nullptr;
     void* _evJoin = nullptr;
     bool _gradPending = false;
+    // The side stream has its own submitting thread: a cross-stream dependency costs ~16 us of host time on this runtime
+    // (tools/sync_cost.hip), most of it in the wait call, and two threads submit to two streams without slowing each
+    // other down.  The main thread records the fork event and hands the closures over; the side thread waits for the
+    // event on the side stream and issues them there.
+    struct SideTask { std::vector<std::function<void()>> fns; void* forkEvent; };
+    std::thread _sideThread;
+    std::mutex _sideMutex;
+    std::condition_variable _sideCv;
+    std::deque<SideTask> _sideQueue;
+    std::atomic<long> _sidePushed{0}, _sideDone{0};
+    bool _sideStop = false;
+    std::exception_ptr _sideError;
+    std::vector<void*> _forkEvents;
+    size_t _forkNext = 0;
+    std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread
+    void sideLoop();
+    void stopSideThread();
+    void checkSideError();
     std::vector<std::pair<std::function<void()>, int>> _deferred;
     int _deferredUnits = 0;
     void flushSideWork(size_t count);  // first `count` deferred items -> side stream (one fork)
@@ -553,7 +576,7 @@ class ConvNet {
     int _sideUnits = 2, _wlSeen = 0, _wlPerPass = 0;
     void* _evGather = nullptr;
     void* _evComm = nullptr;
-    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; };
+    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; bool onSide = false, onMain = true; };
     std::vector<Segment> _segments;  // in arena order (reverse layer order)
     size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
     size_t _bucketFloats = 1 << 20;

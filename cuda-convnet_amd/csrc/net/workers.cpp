@@ -99,6 +99,7 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
     const int nm = _dp->numMinibatches();
     long cases = 0;
     const auto t0 = std::chrono::steady_clock::now();
+    g_eventCallMs = 0;
     try {
         for (int s = 0; s < numSteps; s++) {
             if (_phases) profBegin("phase.forward");
@@ -117,6 +118,8 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
         // host-side submission time of the whole loop (launch-bound when it approaches the wall time)
         res.profile["host.enqueue"].count = numSteps;
         res.profile["host.enqueue"].ms = enq;
+        res.profile["host.events"].count = numSteps;
+        res.profile["host.events"].ms = g_eventCallMs;
     } catch (...) {
         _profiling = _phases = false;
         throw;
