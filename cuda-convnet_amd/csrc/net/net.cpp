@@ -866,13 +866,16 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
 
 ConvNet::~ConvNet() {
     stop();
+    _side.stop();
+    _commSub.stop();
+    if (getenv("MCN_DEBUG_TIMES") && _rcclCalls) fprintf(stderr, "[mcn] all-reduce calls: %ld, host us per call: %.1f\n", (long)_rcclCalls, _rcclCallNs / 1e3 / _rcclCalls);
     if (_comm) mcn_comm_destroy(_comm);
     if (_commStream) mcn_stream_destroy(_commStream);
     if (_evGrad) mcn_event_destroy(_evGrad);
     if (_evGrad2) mcn_event_destroy(_evGrad2);
     if (_evGather) mcn_event_destroy(_evGather);
     if (_evComm) mcn_event_destroy(_evComm);
-    stopSideThread();
+    for (void* e : _bucketEvents) mcn_event_destroy(e);
     if (_gradStream) mcn_stream_destroy(_gradStream);
     for (void* e : _forkEvents) mcn_event_destroy(e);
     if (_evJoin) mcn_event_destroy(_evJoin);
@@ -952,7 +955,7 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
         chk(mcn_event_create_sync(&_evJoin), "event");
         _forkEvents.resize(32, nullptr);
         for (void*& e : _forkEvents) chk(mcn_event_create_sync(&e), "event");
-        _sideThread = std::thread([this] { sideLoop(); });
+        _side.start(_deviceID);
     }
     for (auto& l : _layers) l->copyToGPU();
     buildFusions();
@@ -1029,6 +1032,9 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         chk(mcn_event_create_sync(&_evGrad), "event");
         chk(mcn_event_create_sync(&_evGrad2), "event");
         chk(mcn_event_create_sync(&_evGather), "event");
+        _bucketEvents.resize(16, nullptr);
+        for (void*& e : _bucketEvents) chk(mcn_event_create_sync(&e), "event");
+        _commSub.start(_deviceID);  // waits + RCCL calls are issued by their own thread
         chk(mcn_event_create_sync(&_evComm), "event");
         const char* env = getenv("MCN_BUCKET_MB");
         _bucketFloats = (size_t)((env ? atof(env) : 4.0) * 1024 * 1024 / 4);
@@ -1047,60 +1053,71 @@ static thread_local bool t_sideThread = false;
 void* ConvNet::stream() const { return t_sideThread ? _gradStream : _stream; }
 void* ConvNet::workspace() const { return t_sideThread ? _ws2.p : _ws.p; }
 
-void ConvNet::sideLoop() {
-    t_sideThread = true;
-    mcn_set_device(_deviceID < 0 ? 0 : _deviceID);
+void Submitter::start(int deviceID, bool* sideFlag) {
+    _flag = sideFlag;
+    _thread = std::thread([this, deviceID] { loop(deviceID); });
+}
+
+void Submitter::loop(int deviceID) {
+    mcn_set_device(deviceID < 0 ? 0 : deviceID);
     for (;;) {
-        SideTask task;
+        std::function<void()> fn;
         {
-            std::unique_lock<std::mutex> lk(_sideMutex);
+            std::unique_lock<std::mutex> lk(_mutex);
             // work arrives every few tens of microseconds while a step is being submitted: poll before sleeping
-            for (int spin = 0; _sideQueue.empty() && !_sideStop && spin < 20000; spin++) {
+            for (int spin = 0; _queue.empty() && !_stop && spin < 20000; spin++) {
                 lk.unlock();
                 std::this_thread::yield();
                 lk.lock();
             }
-            _sideCv.wait(lk, [this] { return !_sideQueue.empty() || _sideStop; });
-            if (_sideQueue.empty()) return;  // stop requested
-            task = std::move(_sideQueue.front());
-            _sideQueue.pop_front();
+            _cv.wait(lk, [this] { return !_queue.empty() || _stop; });
+            if (_queue.empty()) return;  // stop requested
+            fn = std::move(_queue.front());
+            _queue.pop_front();
         }
         try {
-            if (!_sideError) {
-                chk(timedStreamWait(_gradStream, task.forkEvent), "wait event");
-                for (auto& fn : task.fns) fn();
-            }
+            if (!_error) fn();
         } catch (...) {
-            std::lock_guard<std::mutex> lk(_sideMutex);
-            if (!_sideError) _sideError = std::current_exception();
+            std::lock_guard<std::mutex> lk(_mutex);
+            if (!_error) _error = std::current_exception();
         }
-        _sideDone.fetch_add(1, std::memory_order_release);
+        _done.fetch_add(1, std::memory_order_release);
     }
 }
 
-void ConvNet::stopSideThread() {
-    if (!_sideThread.joinable()) return;
+void Submitter::stop() {
+    if (!_thread.joinable()) return;
     {
-        std::lock_guard<std::mutex> lk(_sideMutex);
-        _sideStop = true;
+        std::lock_guard<std::mutex> lk(_mutex);
+        _stop = true;
     }
-    _sideCv.notify_all();
-    _sideThread.join();
+    _cv.notify_all();
+    _thread.join();
 }
 
-void ConvNet::checkSideError() {
+long Submitter::push(std::function<void()> fn) {
+    {
+        std::lock_guard<std::mutex> lk(_mutex);
+        _queue.push_back(std::move(fn));
+    }
+    const long t = _pushed.fetch_add(1, std::memory_order_relaxed) + 1;
+    _cv.notify_one();
+    return t;
+}
+
+void Submitter::wait(long ticket) {
+    for (int spin = 0; _done.load(std::memory_order_acquire) < ticket; spin++)
+        if (spin > 64) std::this_thread::yield();
     std::exception_ptr e;
     {
-        std::lock_guard<std::mutex> lk(_sideMutex);
-        std::swap(e, _sideError);
+        std::lock_guard<std::mutex> lk(_mutex);
+        std::swap(e, _error);
     }
     if (e) std::rethrow_exception(e);
 }
 
 void ConvNet::waitSideSubmitted(long ticket) {
-    for (int spin = 0; _sideDone.load(std::memory_order_acquire) < ticket; spin++)
-        if (spin > 64) std::this_thread::yield();
-    checkSideError();
+    if (ticket > 0) _side.wait(ticket);
 }
 
 bool ConvNet::lastWeightLayerOfPass() { return ++_wlSeen == _wlPerPass; }
@@ -1122,30 +1139,29 @@ long ConvNet::forkSideWork(std::function<void()> fn) {
     }
     _deferred.emplace_back(std::move(fn), 0);
     flushSideWork(_deferred.size());  // (together with what was deferred before: keeps the order)
-    return _sidePushed.load(std::memory_order_relaxed);
+    return _side.pushed();
 }
 
 // the first `count` deferred items become one task of the side thread, ordered after everything the main stream
 // holds at this point
 void ConvNet::flushSideWork(size_t count) {
     if (count == 0) return;
-    SideTask task;
-    task.forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
+    void* forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
     // (an event may be recorded again before the side thread has waited for its previous use: that wait then covers
     // more of the main stream than it needs to, never less; 32 events make it rare)
-    chk(timedEventRecord(task.forkEvent, _stream), "event record");
+    chk(timedEventRecord(forkEvent, _stream), "event record");
+    auto fns = std::make_shared<std::vector<std::function<void()>>>();
     for (size_t i = 0; i < count; i++) {
-        task.fns.push_back(std::move(_deferred[i].first));
+        fns->push_back(std::move(_deferred[i].first));
         _deferredUnits -= _deferred[i].second;
     }
     _deferred.erase(_deferred.begin(), _deferred.begin() + count);
     _gradPending = true;
-    {
-        std::lock_guard<std::mutex> lk(_sideMutex);
-        _sideQueue.push_back(std::move(task));
-    }
-    _sidePushed.fetch_add(1, std::memory_order_relaxed);
-    _sideCv.notify_one();
+    _side.push([this, forkEvent, fns] {
+        t_sideThread = true;
+        chk(timedStreamWait(_gradStream, forkEvent), "wait event");
+        for (auto& fn : *fns) fn();
+    });
 }
 
 void ConvNet::finishSideWork() {
@@ -1167,7 +1183,7 @@ void ConvNet::joinGradWork() {
         for (auto& d : rest) d.first();  // on the main stream
     }
     if (!_gradPending) return;
-    waitSideSubmitted(_sidePushed.load(std::memory_order_relaxed));  // the side thread has issued everything it was given
+    _side.wait(_side.pushed());  // the side thread has issued everything it was given
     chk(timedEventRecord(_evJoin, _gradStream), "event record");
     chk(timedStreamWait(_stream, _evJoin), "wait event");
     _gradPending = false;
@@ -1261,15 +1277,27 @@ void ConvNet::flushBuckets(bool force) {
             onMain |= sg.onMain;
             onSide |= sg.onSide;
         }
+    // the producer records (cheap), the exchange thread waits and calls RCCL (expensive)
+    void* evMain = nullptr;
+    void* evSide = nullptr;
     if (onMain) {
-        chk(timedEventRecord(_evGrad, _stream), "event record");
-        chk(timedStreamWait(_commStream, _evGrad), "wait event");
+        evMain = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
+        chk(timedEventRecord(evMain, _stream), "event record");
     }
     if (onSide) {
-        chk(timedEventRecord(_evGrad2, _gradStream), "event record");
-        chk(timedStreamWait(_commStream, _evGrad2), "wait event");
+        evSide = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
+        chk(timedEventRecord(evSide, _gradStream), "event record");
     }
-    chk(mcn_allreduce_sum(_comm, _gradArena.p + _sentUpTo, end - _sentUpTo, _commStream), "all-reduce");
+    float* buf = _gradArena.p + _sentUpTo;
+    const size_t count = end - _sentUpTo;
+    _commSub.push([this, evMain, evSide, buf, count] {
+        if (evMain) chk(mcn_stream_wait_event(_commStream, evMain), "wait event");
+        if (evSide) chk(mcn_stream_wait_event(_commStream, evSide), "wait event");
+        const auto t0 = std::chrono::steady_clock::now();
+        chk(mcn_allreduce_sum(_comm, buf, count, _commStream), "all-reduce");
+        _rcclCallNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        _rcclCalls++;
+    });
     _sentUpTo = end;
     _commPending = true;
 }
@@ -1277,6 +1305,7 @@ void ConvNet::flushBuckets(bool force) {
 void ConvNet::waitComm() {
     std::lock_guard<std::mutex> lk(_commMutex);
     if (_commPending) {
+        _commSub.wait(_commSub.pushed());  // every exchange of this step has been issued
         chk(timedEventRecord(_evComm, _commStream), "event record");
         chk(timedStreamWait(_stream, _evComm), "wait event");
         _commPending = false;
@@ -1288,16 +1317,20 @@ void ConvNet::waitComm() {
 void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
     std::lock_guard<std::mutex> lk(_commMutex);
     // both gathers in one fused RCCL launch on the exchange stream; consumers call waitGather() when they need the result
-    chk(timedEventRecord(_evGrad, stream()), "event record");
-    chk(timedStreamWait(_commStream, _evGrad), "wait event");
-    chk(mcn_comm_group_begin(), "group begin");
-    chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
-    chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
-    chk(mcn_comm_group_end(), "group end");
-    chk(timedEventRecord(_evGather, _commStream), "event record");
+    void* ev = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
+    chk(timedEventRecord(ev, stream()), "event record");
+    _gatherTicket = _commSub.push([this, ev, sendA, recvA, sendB, recvB, countPerRank] {
+        chk(mcn_stream_wait_event(_commStream, ev), "wait event");
+        chk(mcn_comm_group_begin(), "group begin");
+        chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
+        chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
+        chk(mcn_comm_group_end(), "group end");
+        chk(mcn_event_record(_evGather, _commStream), "event record");
+    });
 }
 
 void ConvNet::waitGather() {  // on the stream the caller is enqueueing on
+    _commSub.wait(_gatherTicket);  // the exchange thread has recorded _evGather
     chk(timedStreamWait(stream(), _evGather), "wait event");
 }
 

@@ -448,6 +448,30 @@ class ProfScope {
     ConvNet* _net;
 };
 
+// A submitting thread: runs closures in order (each issues runtime calls on one stream).  HIP scales across host
+// threads that feed different streams (tools/sync_cost.hip), and a cross-stream wait or an RCCL call costs 10-60 us of
+// host time -- too much for the thread that feeds the critical stream.
+class Submitter {
+   public:
+    ~Submitter() { stop(); }
+    void start(int deviceID, bool* sideFlag = nullptr);
+    void stop();
+    bool running() const { return _thread.joinable(); }
+    long push(std::function<void()> fn);  // returns the ticket of this closure
+    long pushed() const { return _pushed.load(std::memory_order_relaxed); }
+    void wait(long ticket);               // host-side: until the closure with that ticket has run; rethrows its error
+   private:
+    void loop(int deviceID);
+    std::thread _thread;
+    std::mutex _mutex;
+    std::condition_variable _cv;
+    std::deque<std::function<void()>> _queue;
+    std::atomic<long> _pushed{0}, _done{0};
+    bool _stop = false;
+    std::exception_ptr _error;
+    bool* _flag = nullptr;
+};
+
 class ConvNet {
    public:
     ConvNet(const std::vector<Params>& layers, int minibatchSize, int deviceID);
@@ -541,20 +565,14 @@ class ConvNet {
     // (tools/sync_cost.hip), most of it in the wait call, and two threads submit to two streams without slowing each
     // other down.  The main thread records the fork event and hands the closures over; the side thread waits for the
     // event on the side stream and issues them there.
-    struct SideTask { std::vector<std::function<void()>> fns; void* forkEvent; };
-    std::thread _sideThread;
-    std::mutex _sideMutex;
-    std::condition_variable _sideCv;
-    std::deque<SideTask> _sideQueue;
-    std::atomic<long> _sidePushed{0}, _sideDone{0};
-    bool _sideStop = false;
-    std::exception_ptr _sideError;
+    Submitter _side, _commSub;  // side stream and exchange stream
     std::vector<void*> _forkEvents;
     size_t _forkNext = 0;
     std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread
-    void sideLoop();
-    void stopSideThread();
-    void checkSideError();
+    std::vector<void*> _bucketEvents;  // ring: producer-side records for the exchange thread to wait on
+    size_t _bucketNext = 0;
+    long _gatherTicket = 0;
+    long _rcclCallNs = 0, _rcclCalls = 0;  // exchange thread only (MCN_DEBUG_TIMES)
     std::vector<std::pair<std::function<void()>, int>> _deferred;
     int _deferredUnits = 0;
     void flushSideWork(size_t count);  // first `count` deferred items -> side stream (one fork)

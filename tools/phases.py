@@ -13,6 +13,8 @@ dp = SyntheticDataProvider(kind, 128 * 16, img=img, minibatch=128, seed=1)
 dims = {i: dp.get_data_dims(i) for i in range(len(dp.dims))}
 layers = layer.parse_layers(os.path.join(CFG_DIR, ldef), os.path.join(CFG_DIR, lpar), dims, dp.get_num_classes(), seed=3)
 lib.initModel(layers, 128, 0)
+if os.environ.get('MCN_PHASES_DP'):
+    lib.initDataParallel(0, 1, lib.commUniqueId(), 1)
 lib.loadBatch(dp.get_next_batch()[2])
 lib.startSteps(20, 0, 0); lib.finishBatch()
 n = 100
