@@ -148,7 +148,7 @@ def main():
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('MCN_BENCH_DEVICE', os.environ.get('LOCAL_RANK', 0)))  # (override: rehearsing ranks on one GPU)
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d' % (a.gpus, a.gpus))
@@ -220,7 +220,7 @@ def main():
                        'final_costs': {k: [x / ncases for x in v] for k, v in costs.items()}},
         }
         if prof:
-            prof.pop('host.enqueue', None)
+            prof = {k: v for k, v in prof.items() if not k.startswith(('host.', 'phase.'))}
             ks = [roofline_entry(layers, lab, c, ms, mb) for lab, (c, ms) in prof.items() if c > 0]
             ks.sort(key=lambda e: -e['avg_us'] * e['launches'])
             step_us = sum(e['avg_us'] * e['launches'] for e in ks) / a.profile_steps

@@ -21,7 +21,8 @@ int mcn_check_hip(hipError_t e, const char* what);
         }                                     \
     } while (0)
 
-#define MCN_LAUNCH_CHECK(name) mcn_check_hip(hipGetLastError(), name)
+int mcn_launch_check(const char* what);  // hipGetLastError + this thread's launch counter (mcn_launch_count)
+#define MCN_LAUNCH_CHECK(name) mcn_launch_check(name)
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline size_t divup_sz(size_t a, size_t b) { return (a + b - 1) / b; }

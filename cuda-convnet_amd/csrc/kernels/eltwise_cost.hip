@@ -534,13 +534,14 @@ MCN_API int mcn_softmax_grad(const float* acts, const float* actsGrad, float* ta
 // data-dependent margin and every 1[d<m] decision agree bit for bit.  Phase 2: getOptimalThr
 // (:482-498) as an O(h) scan per candidate, first strict maximum wins.  Phase 3: cost or gradient.
 #define L2SN_MAX_PAIRS 2048
-#define L2SN_TILE 4096  // floats of squared differences staged per pass
+#define L2SN_TILE 4096       // floats of squared differences staged per pass: at least this many ...
+#define L2SN_TILE_MAX 12288  // ... and up to this many when the 64 KB of LDS allow (DeepID2: all 160 rows in one pass)
 // Pair labels and distances.  The squares are computed by all threads into an LDS tile (independent,
 // coalesced loads); thread j then adds its column of the tile in row order -- the summation order of
 // the reference's SquaredDiff + column-sum and of the CPU oracle.
-__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs, float* sq) {
+__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs, float* sq, int tile) {
     const int h = numCases / 2;
-    const int TR = max(1, L2SN_TILE / h);
+    const int TR = max(1, tile / h);
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
         labs[j] = idens[j] == idens[j + h] ? 1.f : -1.f;
         dists[j] = 0.f;
@@ -554,11 +555,11 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
         const int rows = min(TR, numD - k0);
         __syncthreads();
         if (vec && hq <= (int)blockDim.x) {
-            // batches of 4 independent row loads per thread
-            for (int kb = rq; kb < rows && rq < RV; kb += 4 * RV) {
-                f32x4 gv[4], qv[4];
+            // batches of 8 independent row loads per thread
+            for (int kb = rq; kb < rows && rq < RV; kb += 8 * RV) {
+                f32x4 gv[8], qv[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     const int kk = kb + u * RV;
                     if (kk < rows) {
                         const float* g = data + (size_t)(k0 + kk) * numCases + 4 * jq;
@@ -567,7 +568,7 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < 8; u++) {
                     const int kk = kb + u * RV;
                     if (kk < rows) {
                         f32x4 d = gv[u] - qv[u];
@@ -634,7 +635,7 @@ __device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* r
 template <int MODE>
 __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, const float* __restrict__ data, float* __restrict__ out,
                                               int numD, int numCases, float m, int add, float coeff, float* info, float* pairStats,
-                                              double* costOut, const float* extD, const float* extL, int extCount, int rowsPerBlock) {
+                                              double* costOut, const float* extD, const float* extL, int extCount, int rowsPerBlock, int tile) {
     extern __shared__ float shf[];
     const int h = numCases / 2;
     const int cnt = extD ? extCount : h;
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
     float* sq = (float*)(rates + cnt);           // [L2SN_TILE]
     __shared__ float sh_m[2];
     __shared__ double shsum[256];
-    l2sn_stats(idens, data, numD, numCases, dists, labs, sq);
+    l2sn_stats(idens, data, numD, numCases, dists, labs, sq, tile);
     if (extD) {
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) { cd[i] = extD[i]; cl[i] = extL[i]; }
     }
@@ -709,11 +710,13 @@ static int l2sn_launch(int mode, const float* idens, const float* data, float* o
     MCN_REQUIRE((extD == nullptr) == (extL == nullptr), "l2sn: extDists and extLabels go together");
     const int h = numCases / 2, cnt = extD ? extCount : h;
     MCN_REQUIRE(h <= L2SN_MAX_PAIRS && cnt <= L2SN_MAX_PAIRS && cnt > 0, "l2sn: too many pairs (%d, limit %d)", cnt, L2SN_MAX_PAIRS);
-    const size_t lds = (size_t)(2 * h + (extD ? 2 * cnt : 0) + cnt + L2SN_TILE) * 4;
+    const size_t fixedFloats = (size_t)2 * h + (extD ? 2 * cnt : 0) + cnt;
+    const int tile = (int)std::min<size_t>(L2SN_TILE_MAX, std::max<size_t>(L2SN_TILE, (64 * 1024 - 2304) / 4 - fixedFloats));
+    const size_t lds = (fixedFloats + tile) * 4;
     hipStream_t s = (hipStream_t)stream;
     const int rowsPerBlock = std::max(1, 512 / h);  // two gradient elements per thread
     const int gradBlocks = divup(numD, rowsPerBlock);
-#define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount, rowsPerBlock
+#define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount, rowsPerBlock, tile
     if (mode == 0) hipLaunchKernelGGL((k_l2sn<0>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
     else if (mode == 1) hipLaunchKernelGGL((k_l2sn<1>), dim3(gradBlocks), dim3(256), lds, s, L2SN_ARGS);
     else hipLaunchKernelGGL((k_l2sn<2>), dim3(1), dim3(256), lds, s, L2SN_ARGS);

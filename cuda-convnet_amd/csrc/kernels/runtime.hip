@@ -20,6 +20,13 @@ int mcn_check_hip(hipError_t e, const char* what) {
     return MCN_EHIP;
 }
 
+static thread_local size_t t_launches = 0;
+int mcn_launch_check(const char* what) {
+    t_launches++;
+    return mcn_check_hip(hipGetLastError(), what);
+}
+MCN_API size_t mcn_launch_count(void) { return t_launches; }
+
 MCN_API const char* mcn_last_error(void) { return g_err; }
 
 MCN_API int mcn_device_count(int* count) { return mcn_check_hip(hipGetDeviceCount(count), "hipGetDeviceCount"); }

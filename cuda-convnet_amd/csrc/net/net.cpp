@@ -1357,7 +1357,7 @@ void ConvNet::profBegin(const std::string& label) {
         it = _profLabelIdx.emplace(label, (int)_profLabels.size()).first;
         _profLabels.push_back(label);
     }
-    ProfSpan s{it->second, profEvent(), nullptr};
+    ProfSpan s{it->second, profEvent(), nullptr, mcn_launch_count()};
     chk(timedEventRecord(s.e0, _stream), "event record");
     _profSpans.push_back(s);
 }
@@ -1366,6 +1366,10 @@ void ConvNet::profEnd() {
     // spans nest at most one deep in practice; close the innermost open one
     for (size_t i = _profSpans.size(); i-- > 0;)
         if (!_profSpans[i].e1) {
+            if (!_phases && mcn_launch_count() == _profSpans[i].launches0 && i + 1 == _profSpans.size()) {
+                _profSpans.pop_back();  // nothing was launched inside (an operation fused into its neighbour): not a kernel
+                return;
+            }
             _profSpans[i].e1 = profEvent();
             chk(timedEventRecord(_profSpans[i].e1, _stream), "event record");
             return;

@@ -602,7 +602,7 @@ class ConvNet {
 
     // per-operation event timing (off on the normal path)
     bool _profiling = false, _phases = false;
-    struct ProfSpan { int label; void* e0; void* e1; };
+    struct ProfSpan { int label; void* e0; void* e1; size_t launches0; };
     std::vector<std::string> _profLabels;
     std::map<std::string, int> _profLabelIdx;
     std::vector<ProfSpan> _profSpans;

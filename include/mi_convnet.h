@@ -49,6 +49,8 @@ enum mcn_neuron {
 
 /* ---- runtime (replaces cudaSetDevice/cublasAlloc/cublasSetMatrix... nvmatrix.cu:60-170, convnet.cu:139-145) */
 const char* mcn_last_error(void);
+/* kernel launches this thread has made through the library so far (profilers use it to drop spans that launched nothing) */
+size_t mcn_launch_count(void);
 int mcn_device_count(int* count);
 int mcn_set_device(int device);
 int mcn_alloc(void** ptr, size_t bytes);
