@@ -227,6 +227,14 @@ def main():
             top = dict(ks[0])
             out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'],
                                'frac': top['frac'], 'traffic': None, 'kernel': top['op'], 'avg_us': top['avg_us']}
+            # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
+            # under profiles/ with the gfx950 correction applied (they cannot be collected inside this process)
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_by_op.json')
+            if a.workload == 'deepid2' and mb == 128 and os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(top['op'])
+                if rec:
+                    out['roofline']['traffic'] = rec['traffic_bytes_per_launch']
+                    out['roofline']['traffic_unit'] = 'bytes/launch (PMC, corrected); algorithmic %d' % rec['algorithmic_bytes_per_launch']
             out['device_us_per_step'] = round(step_us, 1)
             out['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
