@@ -28,7 +28,8 @@ template <int CV, int NQ, bool VECN, int U>
 __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const int px = blockIdx.y * 4 + wave;
     if (px >= imgPixels) return;
     const int y = px / p.imgX, x = px % p.imgX;

@@ -22,8 +22,11 @@ struct BwdWParams {
     float sT, sO;
 };
 
-template <int KV, int FV, bool VECN>
+// MODE 0: scalar loads (any N / alignment); 1: 16-byte loads through pointers; 2: 16-byte buffer loads -- lanes outside
+// the matrix get an out-of-range offset and read zero, so the loop body has no branches (buffers below 2 GB).
+template <int KV, int FV, int MODE>
 __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
+    constexpr bool VECN = MODE >= 1;
     extern __shared__ int tbl[];
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int K = fc * fp, M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
         }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const int kt = blockIdx.y;
     const int chunk = blockIdx.x;
     const int f0 = blockIdx.z * (16 * FV);
@@ -68,45 +72,84 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
     // (chunks of fewer than four modules -- the unshared local layers -- split the images instead)
     const bool splitN = p.modulesPerChunk < 4;
     const int mStep = splitN ? 1 : 4, nStep = splitN ? 64 : 16;
-    for (int m = mBeg + (splitN ? 0 : wave); m < mEnd; m += mStep) {
-        const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
-        const float* arow[KV];
-        bool ainb[KV];
-#pragma unroll
-        for (int v = 0; v < KV; v++) {
-            ainb[v] = kb + 16 * v + j < K;
-            if (check) ainb[v] = ainb[v] && (unsigned)(y0 + (yx[v] >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx[v] & 0xffff)) < (unsigned)p.imgX;
-            arow[v] = ig + ((ptrdiff_t)off[v] + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride;
-        }
-        const float* hm = hg + (size_t)m * p.N;
-        for (int nb = splitN ? 16 * wave : 0; nb < p.N; nb += nStep) {
-            const int n = nb + 4 * kk;
-            f32x4 a[KV], b[FV];
+    if constexpr (MODE == 2) {
+        const size_t imgBytes = ((size_t)(fc * imgPixels - 1) * p.imgStride + p.N) * 4;
+        const __amdgpu_buffer_rsrc_t rImg = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.images + (ptrdiff_t)grp * fc * imgPixels * p.imgStride), 0, (int)imgBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rHid = __builtin_amdgcn_make_buffer_rsrc((void*)p.hidActs, 0, (int)((size_t)p.F * M * p.N * 4), 0x00020000);
+        const unsigned OOB = 0xFFFFFFF0u;
+        const unsigned hstep = (unsigned)((size_t)16 * M * p.N * 4);
+        // (Issuing several iterations' loads at once was measured slower, 24.7 -> 31 us on conv1: the kernel is bound by
+        // cache-line requests -- every load touches 16 rows x 64 B -- not by the latency of one round trip.)
+        for (int m = mBeg + (splitN ? 0 : wave); m < mEnd; m += mStep) {
+            const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
+            unsigned aoff[KV];
+            bool ainb[KV];
 #pragma unroll
             for (int v = 0; v < KV; v++) {
-                if (VECN) {
-                    a[v] = (ainb[v] && n < p.N) ? *reinterpret_cast<const f32x4*>(arow[v] + nb) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) a[v][t] = (ainb[v] && n + t < p.N) ? arow[v][nb + t] : 0.f;
-                }
+                ainb[v] = kb + 16 * v + j < K;
+                if (check) ainb[v] = ainb[v] && (unsigned)(y0 + (yx[v] >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx[v] & 0xffff)) < (unsigned)p.imgX;
+                aoff[v] = (unsigned)((off[v] + y0 * p.imgX + x0) * p.imgStride + 4 * kk) * 4u;
             }
-#pragma unroll
-            for (int u = 0; u < FV; u++) {
-                const float* hr = hm + (size_t)(16 * u) * M * p.N + nb;
-                if (VECN) {
-                    b[u] = n < p.N ? *reinterpret_cast<const f32x4*>(hr) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) b[u][t] = n + t < p.N ? hr[t] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; t++)
+            const unsigned hoff = (unsigned)(((size_t)(f0 + j) * M + m) * p.N + 4 * kk) * 4u;
+            for (int nb = splitN ? 16 * wave : 0; nb < p.N; nb += nStep) {
+                const bool nin = nb + 4 * kk < p.N;
+                f32x4 a[KV], b[FV];
 #pragma unroll
                 for (int v = 0; v < KV; v++)
+                    a[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rImg, (ainb[v] && nin) ? aoff[v] + 4u * nb : OOB, 0, 0));
 #pragma unroll
-                    for (int u = 0; u < FV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+                for (int u = 0; u < FV; u++)
+                    b[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rHid, nin ? hoff + u * hstep + 4u * nb : OOB, 0, 0));
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int v = 0; v < KV; v++)
+#pragma unroll
+                        for (int u = 0; u < FV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+            }
+        }
+    } else {
+    for (int m = mBeg + (splitN ? 0 : wave); m < mEnd; m += mStep) {
+            const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
+            const float* arow[KV];
+            bool ainb[KV];
+#pragma unroll
+            for (int v = 0; v < KV; v++) {
+                ainb[v] = kb + 16 * v + j < K;
+                if (check) ainb[v] = ainb[v] && (unsigned)(y0 + (yx[v] >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx[v] & 0xffff)) < (unsigned)p.imgX;
+                arow[v] = ig + ((ptrdiff_t)off[v] + (ptrdiff_t)y0 * p.imgX + x0) * p.imgStride;
+            }
+            const float* hm = hg + (size_t)m * p.N;
+            for (int nb = splitN ? 16 * wave : 0; nb < p.N; nb += nStep) {
+                const int n = nb + 4 * kk;
+                f32x4 a[KV], b[FV];
+#pragma unroll
+                for (int v = 0; v < KV; v++) {
+                    if (VECN) {
+                        a[v] = (ainb[v] && n < p.N) ? *reinterpret_cast<const f32x4*>(arow[v] + nb) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) a[v][t] = (ainb[v] && n + t < p.N) ? arow[v][nb + t] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FV; u++) {
+                    const float* hr = hm + (size_t)(16 * u) * M * p.N + nb;
+                    if (VECN) {
+                        b[u] = n < p.N ? *reinterpret_cast<const f32x4*>(hr) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++) b[u][t] = n + t < p.N ? hr[t] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int v = 0; v < KV; v++)
+#pragma unroll
+                        for (int u = 0; u < FV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+            }
         }
     }
 
@@ -178,8 +221,11 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__
 
 template <int KV, int FV>
 static void launch_bw2(const BwdWParams& p, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
-    if (vecn) hipLaunchKernelGGL((k_weight_acts<KV, FV, true>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_weight_acts<KV, FV, false>), grid, dim3(256), lds, s, p);
+    const size_t imgBytes = (size_t)p.C * p.imgY * p.imgX * p.imgStride * 4, hidBytes = (size_t)p.F * p.mY * p.mX * p.N * 4;
+    const bool buf = vecn && imgBytes < (1u << 31) && hidBytes < (1u << 31);
+    if (buf) hipLaunchKernelGGL((k_weight_acts<KV, FV, 2>), grid, dim3(256), lds, s, p);
+    else if (vecn) hipLaunchKernelGGL((k_weight_acts<KV, FV, 1>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_weight_acts<KV, FV, 0>), grid, dim3(256), lds, s, p);
 }
 
 static int weight_acts_check(const float* images, const float* hidActs, float* targets, int N, int imgStride,
@@ -267,7 +313,7 @@ MCN_API int mcn_local_weight_acts(const float* images, const float* hidActs, flo
 static int reduced_modules_per_chunk(int M, int K, int F) {
     const long tilesPerChunk = (long)divup(K, 48) * (F / 16);
     long want = divup(1024, (int)(tilesPerChunk > 0 ? tilesPerChunk : 1));  // chunks wanted (a chunk is a 4-wave block per tile)
-    if (want > M / 8) want = M / 8 > 0 ? M / 8 : 1;                         // at least two modules per wave
+    if (want > M / 4) want = M / 4 > 0 ? M / 4 : 1;                         // at least one module per wave (measured: conv2 23.1 -> 19.4 us vs two)
     if (want < 1) want = 1;
     if (want > M) want = M;
     return divup(M, (int)want);

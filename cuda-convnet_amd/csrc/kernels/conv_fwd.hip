@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
         }
     }
     __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     // KSPLIT: the four waves of the block share one module and take its k-batches round-robin (summed
     // through LDS below); otherwise each wave owns its own module.
     const int m = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;

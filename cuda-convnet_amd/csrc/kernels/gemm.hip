@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512) void k_gemm_nn(const GemmParams p) {
     extern __shared__ f32x4 red[];
     constexpr int T = MV * NQ * 4;
     const int NW = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const int m0 = blockIdx.y * 16 * MV, n0 = blockIdx.x * 64 * NQ;
     const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     const bool vec = p.vec != 0;
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(512) void k_gemm_tn(const GemmParams p) {
     extern __shared__ f32x4 red[];
     constexpr int T = 4 * NQ * 4;
     const int NW = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64 * NQ;
     const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     const bool vec = p.vec != 0, avec = p.avec != 0;
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(512) void k_gemm_nt(const GemmParams p) {
     extern __shared__ f32x4 red[];
     constexpr int T = MV * NV;
     const int NW = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const int m0 = blockIdx.y * 16 * MV, n0 = blockIdx.x * 16 * NV;
     const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     const bool vec = p.vec != 0;
