@@ -607,11 +607,17 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
 }
 // returns (m, idx) in sh_m[0..1]; candidates/labels of length cnt
 __device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* rates, float* sh_m) {
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const float curr = cd[i];
+    // four lanes share a candidate and count a quarter of the pairs each (integer counts: any order is exact)
+    const int part = threadIdx.x & 3;
+    for (int i0 = 0; i0 < cnt; i0 += blockDim.x >> 2) {
+        const int i = i0 + (threadIdx.x >> 2);
+        const float curr = cd[min(i, cnt - 1)];
         int rate = 0;
-        for (int j = 0; j < cnt; j++) rate += ((cd[j] < curr && cl[j] == 1.f) || (cd[j] > curr && cl[j] == -1.f)) ? 1 : 0;
-        rates[i] = rate;
+#pragma unroll 8
+        for (int j = part; j < cnt; j += 4) rate += ((cd[j] < curr && cl[j] == 1.f) || (cd[j] > curr && cl[j] == -1.f)) ? 1 : 0;
+        rate += __shfl_xor(rate, 1, 64);
+        rate += __shfl_xor(rate, 2, 64);
+        if (part == 0 && i < cnt) rates[i] = rate;
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // first strict maximum: largest rate, lowest index among equals

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""HIP-event time of the small cost / reduction kernels at the DeepID2 shapes (N = 128)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from kbench import timeit, capi, call, dev, dev_empty, ws_bytes  # noqa: E402
+from kutil import dev_double  # noqa: E402
+N, D, K = 128, 160, 10575
+rng = np.random.default_rng(0)
+f = dev((rng.standard_normal((D, N)) * 0.3).astype(np.float32))
+ids = rng.integers(0, K, (1, N)); ids[0, 64:96] = ids[0, :32]
+ids = dev(ids.astype(np.float32))
+out, info, stats, cost = dev_empty((1, 64), 0), dev_empty(4, 0), dev_empty(128, 0), dev_double(2)
+tgt = dev_empty((D, N), 0)
+def show(name, fn): print('%-34s %7.2f us' % (name, timeit(fn)), flush=True)
+show('l2sn pair stats', lambda: call('mcn_l2sn_pair_stats', ids, f, stats, D, N, None))
+show('l2sn cost (m = -1)', lambda: call('mcn_l2sn_cost', ids, f, out, D, N, -1.0, info, stats, cost, None, None, 0, None))
+show('l2sn cost (m = 3)', lambda: call('mcn_l2sn_cost', ids, f, out, D, N, 3.0, info, stats, cost, None, None, 0, None))
+show('l2sn grad (recompute)', lambda: call('mcn_l2sn_grad', ids, f, tgt, D, N, -1.0, 0, 0.0025, None, None, 0, None))
+show('l2sn grad from stats', lambda: call('mcn_l2sn_grad_from_stats', f, tgt, D, N, stats, info, 0, 0.0025, None))
+x = dev(rng.standard_normal((K, N)).astype(np.float32)); p = dev_empty((K, N), 0)
+nb = max(ws_bytes('mcn_softmax_workspace_bytes', K, N), ws_bytes('mcn_logreg_cost_workspace_bytes', K, N))
+ws = capi.workspace(nb)
+show('softmax 10575 x 128', lambda: call('mcn_softmax', x, p, K, N, ws, nb, None))
