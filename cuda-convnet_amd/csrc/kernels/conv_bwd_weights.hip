@@ -308,6 +308,190 @@ MCN_API int mcn_local_weight_acts(const float* images, const float* hidActs, flo
                               1, scaleTargets, scaleOutput, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared-weight conv, strip form.  The per-module kernel above reads every 4x4 (3x3) image patch again for every
+// module: 66 MB of patch rows for conv1 against 4.6 MB of image (PMC: 58 MB of HBM-side traffic per launch).  Here a
+// block owns a STRIP of MS consecutive modules of one module row, CB channels and 16*FV filters, and walks the images
+// in stages of 32: the (CB * fs * W) image rows the strip touches (W = (MS-1)*stride + fs columns) and the strip's
+// gradient rows are loaded once per stage with full 128-byte lines into LDS, and every module's MFMA operands are
+// read from there.  Next stage's global loads are in flight (registers) while the current stage computes.
+// Waves take the strip's modules round-robin; their accumulators are summed through LDS in a fixed order.
+// Output: one (K, F) slab per strip, reduced by k_reduce_chunks.
+struct StripParams {
+    const float* images;
+    const float* hidActs;
+    float* targets;
+    int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride;
+    int MS, CB, W, stripsPerRow;
+    float sO;
+};
+
+template <int KT, int FV>
+__global__ __launch_bounds__(256) void k_conv_wgrad_strip(const StripParams p) {
+    extern __shared__ float lds[];
+    constexpr int RS = 36;     // floats per LDS row: 32 images + 4 of padding (bank spread)
+    constexpr int PI = 8;      // image-row load passes (32 rows each) a thread can hold
+    constexpr int PH = 4 * FV; // gradient-row load passes (MS <= 8)
+    const int fp = p.fs * p.fs, Kb = p.CB * fp, K = p.C * fp, M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
+    const int R = p.CB * p.fs * p.W;  // image rows of the tile; row R stays zero
+    const int HR = 16 * FV * p.MS;
+    float* imgT = lds;
+    float* hidT = lds + (size_t)(R + 1) * RS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int strip = blockIdx.x, my = strip / p.stripsPerRow, mx0 = (strip % p.stripsPerRow) * p.MS;
+    const int msCount = min(p.MS, p.mX - mx0);
+    const int c0 = blockIdx.y * p.CB, f0 = blockIdx.z * (16 * FV);
+    const int y0 = p.pad + my * p.stride, x0 = p.pad + mx0 * p.stride;
+
+    const __amdgpu_buffer_rsrc_t rImg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.images, 0, (int)(((size_t)(p.C * imgPixels - 1) * p.imgStride + p.N) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rHid = __builtin_amdgcn_make_buffer_rsrc((void*)p.hidActs, 0, (int)((size_t)p.F * M * p.N * 4), 0x00020000);
+    const unsigned OOB = 0xFFFFFFF0u;
+
+    // global -> LDS: thread (row r0 + 32*pass, 16-byte column l8) of the two tiles
+    const int l8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    unsigned ioff[PI], hoff[PH];
+#pragma unroll
+    for (int q = 0; q < PI; q++) {
+        const int r = r0 + 32 * q;
+        ioff[q] = OOB;
+        if (r < R) {
+            const int c = r / (p.fs * p.W), rem = r % (p.fs * p.W), fy = rem / p.W, col = rem % p.W;
+            const int y = y0 + fy, x = x0 + col;
+            if ((unsigned)y < (unsigned)p.imgY && (unsigned)x < (unsigned)p.imgX)
+                ioff[q] = (unsigned)(((c0 + c) * imgPixels + y * p.imgX + x) * p.imgStride + 4 * l8) * 4u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PH; q++) {
+        const int r = r0 + 32 * q;
+        hoff[q] = OOB;
+        if (r < HR) {
+            const int f = r / p.MS, ms = r % p.MS;
+            if (ms < msCount) hoff[q] = (unsigned)(((size_t)(f0 + f) * M + my * p.mX + mx0 + ms) * p.N + 4 * l8) * 4u;
+        }
+    }
+    if (threadIdx.x < RS) imgT[(size_t)R * RS + threadIdx.x] = 0.f;
+
+    // MFMA operand rows: tile v, lane row j <-> weight row k = 16v + j of this channel block
+    int rb[KT];
+    bool rv[KT];
+#pragma unroll
+    for (int v = 0; v < KT; v++) {
+        const int k = 16 * v + j;
+        rv[v] = k < Kb;
+        const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
+        rb[v] = (c * p.fs + fy) * p.W + fx;
+    }
+    f32x4 acc[KT][FV];
+#pragma unroll
+    for (int v = 0; v < KT; v++)
+#pragma unroll
+        for (int u = 0; u < FV; u++) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ireg[PI], hreg[PH];
+    auto load_stage = [&](int st) {
+        const unsigned nbyte = (unsigned)st * 128u;
+#pragma unroll
+        for (int q = 0; q < PI; q++)
+            if (32 * q < R)  // block-uniform
+                ireg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rImg, ioff[q] == OOB ? OOB : ioff[q] + nbyte, 0, 0));
+#pragma unroll
+        for (int q = 0; q < PH; q++)
+            if (32 * q < HR)
+                hreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rHid, hoff[q] == OOB ? OOB : hoff[q] + nbyte, 0, 0));
+    };
+    const int stages = p.N / 32;
+    load_stage(0);
+    for (int st = 0; st < stages; st++) {
+        __syncthreads();  // the previous stage's operands have been read
+#pragma unroll
+        for (int q = 0; q < PI; q++)
+            if (r0 + 32 * q < R) *reinterpret_cast<f32x4*>(imgT + (size_t)(r0 + 32 * q) * RS + 4 * l8) = ireg[q];
+#pragma unroll
+        for (int q = 0; q < PH; q++)
+            if (r0 + 32 * q < HR) *reinterpret_cast<f32x4*>(hidT + (size_t)(r0 + 32 * q) * RS + 4 * l8) = hreg[q];
+        __syncthreads();
+        if (st + 1 < stages) load_stage(st + 1);
+        for (int ms = wave; ms < msCount; ms += 4) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                f32x4 a[KT], b[FV];
+#pragma unroll
+                for (int v = 0; v < KT; v++)
+                    a[v] = *reinterpret_cast<const f32x4*>(imgT + (size_t)(rv[v] ? rb[v] + ms * p.stride : R) * RS + 16 * i + 4 * kk);
+#pragma unroll
+                for (int u = 0; u < FV; u++)
+                    b[u] = *reinterpret_cast<const f32x4*>(hidT + (size_t)((16 * u + j) * p.MS + ms) * RS + 16 * i + 4 * kk);
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int v = 0; v < KT; v++)
+#pragma unroll
+                        for (int u = 0; u < FV; u++) acc[v][u] = mfma16(a[v][t], b[u][t], acc[v][u]);
+            }
+        }
+    }
+
+    // fixed-order sum of the four waves' accumulators: wave 0 + wave 1 + wave 2 + wave 3
+    __syncthreads();
+    for (int w = 1; w < 4; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int v = 0; v < KT; v++)
+#pragma unroll
+                for (int u = 0; u < FV; u++) *reinterpret_cast<f32x4*>(lds + ((v * FV + u) * 64 + lane) * 4) = acc[v][u];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int v = 0; v < KT; v++)
+#pragma unroll
+                for (int u = 0; u < FV; u++) acc[v][u] += *reinterpret_cast<const f32x4*>(lds + ((v * FV + u) * 64 + lane) * 4);
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+#pragma unroll
+    for (int v = 0; v < KT; v++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kl = 16 * v + 4 * kk + r;
+            if (kl >= Kb) continue;
+            float* trow = p.targets + ((size_t)strip * K + c0 * fp + kl) * p.F + f0 + j;
+#pragma unroll
+            for (int u = 0; u < FV; u++) trow[16 * u] = p.sO * acc[v][u][r];
+        }
+}
+
+struct StripPlan { bool ok; int MS, CB, FV, KT, W, stripsPerRow, strips; size_t lds; };
+static StripPlan strip_plan(int C, int F, int fs, int mY, int mX, int stride, int groups) {
+    StripPlan pl = {};
+    if (groups != 1 || F % 16 != 0) return pl;
+    pl.MS = std::min(6, mX);  // measured on conv1 (tools/kbench.py): 8 -> 18.9 us, 6 -> 18.1, 4 -> 18.9, 2 -> 26.7
+    pl.W = (pl.MS - 1) * stride + fs;
+    pl.stripsPerRow = divup(mX, pl.MS);
+    pl.strips = mY * pl.stripsPerRow;
+    // all channels in one block: with channel blocks the gradient rows are read once per block and the 16-row tiles
+    // fill badly (conv2: 19.3 us per module vs 25.8 us in strips), so deeper layers stay with the per-module kernel
+    for (int fv = ((F / 16) % 2 == 0 ? 2 : 1); fv >= 1 && !pl.ok; fv--)
+        for (int cb = C; cb >= C; cb--) {
+            const int Kb = cb * fs * fs, KT = divup(Kb, 16), R = cb * fs * pl.W;
+            const size_t lds = std::max((size_t)(R + 1 + 16 * fv * pl.MS) * 36 * 4, (size_t)KT * fv * 64 * 16);
+            if (KT > 5 || R > 256 || lds > 60 * 1024) continue;
+            pl.ok = true; pl.CB = cb; pl.FV = fv; pl.KT = KT; pl.lds = lds;
+            break;
+        }
+    return pl;
+}
+
+template <int KT>
+static void launch_strip(const StripParams& p, const StripPlan& pl, dim3 grid, hipStream_t s) {
+    if (pl.FV == 2) hipLaunchKernelGGL((k_conv_wgrad_strip<KT, 2>), grid, dim3(256), pl.lds, s, p);
+    else hipLaunchKernelGGL((k_conv_wgrad_strip<KT, 1>), grid, dim3(256), pl.lds, s, p);
+}
+
 // module split of the fused reduction: enough chunks to fill the chip, few enough to keep the
 // second pass negligible
 static int reduced_modules_per_chunk(int M, int K, int F) {
@@ -323,7 +507,9 @@ MCN_API size_t mcn_conv_weight_acts_reduced_workspace_bytes(int numImgColors, in
                                                             int numModulesY, int numModulesX, int numGroups) {
     const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
     const int mpc = reduced_modules_per_chunk(M, K, numFilters);
-    return (size_t)divup(M, mpc) * K * numFilters * sizeof(float);
+    const StripPlan pl = strip_plan(numImgColors, numFilters, filterSize, numModulesY, numModulesX, 1, numGroups);
+    const size_t chunks = std::max<size_t>(divup(M, mpc), pl.ok ? pl.strips : 0);  // either form may be chosen at launch
+    return chunks * K * numFilters * sizeof(float);
 }
 
 MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, float* grad, void* workspace,
@@ -335,6 +521,38 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
                                numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
     if (rc) return rc;
     const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
+    const int cols = K * numFilters;
+    // strip form: unit-stride conv, 16-byte image accesses, whole stages of 32 images, buffers within 2 GB
+    const StripPlan pl = strip_plan(numImgColors, numFilters, filterSize, numModulesY, numModulesX, moduleStride, numGroups);
+    const bool vecn = (numImages % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)hidActs) % 16 == 0);
+    const size_t imgBytes = (size_t)numImgColors * imgSizeY * imgSizeX * imgStride * 4, hidBytes = (size_t)numFilters * M * numImages * 4;
+    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31) &&
+        getenv("MCN_NO_WGRAD_STRIP") == nullptr) {
+        const size_t needS = (size_t)pl.strips * cols * sizeof(float);
+        if (workspaceBytes < needS || !workspace) {
+            mcn_set_error("convWeightActsReduced: workspace %zu < %zu bytes", workspaceBytes, needS);
+            return MCN_EWORKSPACE;
+        }
+        StripParams sp;
+        sp.images = images; sp.hidActs = hidActs; sp.targets = (float*)workspace;
+        sp.N = numImages; sp.imgStride = imgStride; sp.imgY = imgSizeY; sp.imgX = imgSizeX; sp.C = numImgColors; sp.F = numFilters;
+        sp.fs = filterSize; sp.mY = numModulesY; sp.mX = numModulesX; sp.pad = paddingStart; sp.stride = moduleStride;
+        sp.MS = pl.MS; sp.CB = pl.CB; sp.W = pl.W; sp.stripsPerRow = pl.stripsPerRow; sp.sO = scaleOutput;
+        dim3 grid(pl.strips, numImgColors / pl.CB, numFilters / (16 * pl.FV));
+        MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "convWeightActsReduced: grid too large");
+        hipStream_t s = (hipStream_t)stream;
+        switch (pl.KT) {
+            case 1: launch_strip<1>(sp, pl, grid, s); break;
+            case 2: launch_strip<2>(sp, pl, grid, s); break;
+            case 3: launch_strip<3>(sp, pl, grid, s); break;
+            case 4: launch_strip<4>(sp, pl, grid, s); break;
+            default: launch_strip<5>(sp, pl, grid, s); break;
+        }
+        rc = MCN_LAUNCH_CHECK("convWeightActsReduced");
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, s, (const float*)workspace, grad, pl.strips, cols, scaleTargets);
+        return MCN_LAUNCH_CHECK("convWeightActsReduced");
+    }
     const int mpc = reduced_modules_per_chunk(M, K, numFilters);
     const int chunks = divup(M, mpc);
     const size_t need = (size_t)chunks * K * numFilters * sizeof(float);
@@ -346,7 +564,6 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
                             numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
                             mpc, 0.f, scaleOutput, (hipStream_t)stream);
     if (rc) return rc;
-    const int cols = K * numFilters;
     hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, grad, chunks, cols, scaleTargets);
     return MCN_LAUNCH_CHECK("convWeightActsReduced");
