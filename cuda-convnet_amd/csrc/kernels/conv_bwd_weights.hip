@@ -526,8 +526,7 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
     const StripPlan pl = strip_plan(numImgColors, numFilters, filterSize, numModulesY, numModulesX, moduleStride, numGroups);
     const bool vecn = (numImages % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)hidActs) % 16 == 0);
     const size_t imgBytes = (size_t)numImgColors * imgSizeY * imgSizeX * imgStride * 4, hidBytes = (size_t)numFilters * M * numImages * 4;
-    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31) &&
-        getenv("MCN_NO_WGRAD_STRIP") == nullptr) {
+    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31)) {
         const size_t needS = (size_t)pl.strips * cols * sizeof(float);
         if (workspaceBytes < needS || !workspace) {
             mcn_set_error("convWeightActsReduced: workspace %zu < %zu bytes", workspaceBytes, needS);
