@@ -705,6 +705,17 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
     _extCount = gather ? h * G : 0;
     if (gather) _gathered.ensure((size_t)2 * h * G);
     float *idens = _inputs[0], *data = _inputs[1];
+    _readyOnExchange = gather && _net->exchangeThreadUsable();
+    if (_readyOnExchange) {
+        _readyTicket = _net->forkExchangeWork([this, idens, data, D, n, h, G] {
+            void* st = _net->stream();  // the exchange stream: statistics, gather, margin search and cost in stream order
+            chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, st), "l2sn pair stats");
+            _net->gatherPairsHere(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
+            chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, nullptr, dCost, _gathered.p, _gathered.p + _extCount, _extCount, st), "l2sn cost");
+            chk(mcn_event_record(_evReady, st), "event record");
+        });
+        return;
+    }
     _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather] {
         if (gather) {
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
@@ -719,8 +730,10 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
-    _net->waitSideSubmitted(_readyTicket);  // the side thread has recorded _evReady
+    if (_readyOnExchange) _net->waitExchangeSubmitted(_readyTicket);  // that thread has recorded _evReady
+    else _net->waitSideSubmitted(_readyTicket);
     chk(timedStreamWait(_net->stream(), _evReady), "wait event");
+    if (_readyOnExchange) _net->exchangeWorkJoined();  // the main stream now follows everything that task issued
     chk(mcn_l2sn_grad_from_stats(_prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(), _pairStats.p,
                                  _info.p, scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2sn grad");
 }
@@ -874,6 +887,7 @@ ConvNet::~ConvNet() {
     if (_evGrad) mcn_event_destroy(_evGrad);
     if (_evGrad2) mcn_event_destroy(_evGrad2);
     if (_evGather) mcn_event_destroy(_evGather);
+    if (_evJoinComm) mcn_event_destroy(_evJoinComm);
     if (_evComm) mcn_event_destroy(_evComm);
     for (void* e : _bucketEvents) mcn_event_destroy(e);
     if (_gradStream) mcn_stream_destroy(_gradStream);
@@ -1032,6 +1046,7 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         chk(mcn_event_create_sync(&_evGrad), "event");
         chk(mcn_event_create_sync(&_evGrad2), "event");
         chk(mcn_event_create_sync(&_evGather), "event");
+        chk(mcn_event_create_sync(&_evJoinComm), "event");
         _bucketEvents.resize(16, nullptr);
         for (void*& e : _bucketEvents) chk(mcn_event_create_sync(&e), "event");
         _commSub.start(_deviceID);  // waits + RCCL calls are issued by their own thread
@@ -1048,10 +1063,10 @@ void ConvNet::sync() {
 }
 
 // ---- side-stream submission -----------------------------------------------------------------
-static thread_local bool t_sideThread = false;
+static thread_local int t_stream = 0;  // which stream this submitting thread feeds: 0 main, 1 side, 2 exchange
 
-void* ConvNet::stream() const { return t_sideThread ? _gradStream : _stream; }
-void* ConvNet::workspace() const { return t_sideThread ? _ws2.p : _ws.p; }
+void* ConvNet::stream() const { return t_stream == 1 ? _gradStream : t_stream == 2 ? _commStream : _stream; }
+void* ConvNet::workspace() const { return t_stream == 1 ? _ws2.p : _ws.p; }  // (exchange-thread work uses no workspace)
 
 void Submitter::start(int deviceID, bool* sideFlag) {
     _flag = sideFlag;
@@ -1158,10 +1173,43 @@ void ConvNet::flushSideWork(size_t count) {
     _deferred.erase(_deferred.begin(), _deferred.begin() + count);
     _gradPending = true;
     _side.push([this, forkEvent, fns] {
-        t_sideThread = true;
+        t_stream = 1;
         chk(timedStreamWait(_gradStream, forkEvent), "wait event");
         for (auto& fn : *fns) fn();
     });
+}
+
+// Work for the exchange stream, ordered after everything the main stream holds now (data-parallel L2-SN: pair statistics,
+// all-gather, margin search and cost in ONE hop to one thread -- through the side thread it took three hops and kept
+// that thread from issuing the gradients of fc6 / fc5).
+long ConvNet::forkExchangeWork(std::function<void()> fn) {
+    void* forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
+    chk(timedEventRecord(forkEvent, _stream), "event record");
+    _exchangeWorkPending = true;
+    return _commSub.push([this, forkEvent, fn] {
+        t_stream = 2;
+        chk(mcn_stream_wait_event(_commStream, forkEvent), "wait event");
+        fn();
+    });
+}
+
+void ConvNet::waitExchangeSubmitted(long ticket) {
+    if (ticket > 0) _commSub.wait(ticket);
+}
+
+void ConvNet::gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
+    chk(mcn_comm_group_begin(), "group begin");
+    chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
+    chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
+    chk(mcn_comm_group_end(), "group end");
+}
+
+void ConvNet::joinExchange() {
+    if (!_exchangeWorkPending) return;
+    _commSub.wait(_commSub.pushed());
+    chk(timedEventRecord(_evJoinComm, _commStream), "event record");
+    chk(timedStreamWait(_stream, _evJoinComm), "wait event");
+    _exchangeWorkPending = false;
 }
 
 void ConvNet::finishSideWork() {
@@ -1182,6 +1230,7 @@ void ConvNet::joinGradWork() {
         _deferredUnits = 0;
         for (auto& d : rest) d.first();  // on the main stream
     }
+    joinExchange();
     if (!_gradPending) return;
     _side.wait(_side.pushed());  // the side thread has issued everything it was given
     chk(timedEventRecord(_evJoin, _gradStream), "event record");
@@ -1251,8 +1300,8 @@ void ConvNet::gradReady(WeightLayer* l) {
                 s.ready = true;
                 // which stream(s) hold the kernels that wrote it: the side thread issues both of a layer's pieces on the
                 // side stream; on the main thread the bias piece may have gone to the side stream (last layer of a pass)
-                s.onSide = t_sideThread || _gradPending;
-                s.onMain = !t_sideThread;
+                s.onSide = t_stream == 1 || _gradPending;
+                s.onMain = t_stream != 1;
             }
     }
     flushBuckets(false);

@@ -339,6 +339,7 @@ class L2SNCostLayer : public CostLayer {
     DBuf _gathered;          // data-parallel: the all-gathered margin candidates
     void* _evReady = nullptr;  // recorded after the cost launch, on whichever stream ran it
     long _readyTicket = 0;
+    bool _readyOnExchange = false;
     int _extCount = 0;
 };
 
@@ -535,6 +536,12 @@ class ConvNet {
     void waitGather();
     long forkSideWork(std::function<void()> fn);  // starts now, on the side stream; returns a ticket for waitSideSubmitted
     void waitSideSubmitted(long ticket);          // host-side: until the side thread has issued that work
+    bool exchangeThreadUsable() const { return _dpOn && _gradStream && !_profiling && _commSub.running(); }
+    long forkExchangeWork(std::function<void()> fn);  // on the exchange stream / thread (data parallel)
+    void waitExchangeSubmitted(long ticket);
+    void gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // exchange thread only
+    void joinExchange();
+    void exchangeWorkJoined() { _exchangeWorkPending = false; }
     void setFusion(bool on) { _fusion = on; }
     bool profiling() const { return _profiling; }
     void profBegin(const std::string& label);
@@ -572,6 +579,8 @@ class ConvNet {
     std::vector<void*> _bucketEvents;  // ring: producer-side records for the exchange thread to wait on
     size_t _bucketNext = 0;
     long _gatherTicket = 0;
+    bool _exchangeWorkPending = false;
+    void* _evJoinComm = nullptr;
     long _rcclCallNs = 0, _rcclCalls = 0;  // exchange thread only (MCN_DEBUG_TIMES)
     std::vector<std::pair<std::function<void()>, int>> _deferred;
     int _deferredUnits = 0;
