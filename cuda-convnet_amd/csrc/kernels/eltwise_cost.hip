@@ -337,14 +337,18 @@ __device__ __forceinline__ void softmax_merge16(const f32x2* pp, int numCases, i
 #pragma unroll
     for (int k = 0; k < 16; k++) S += (shm[k][cl] == -INFINITY) ? 0.f : shs[k][cl] * expf(shm[k][cl] - M);
 }
+// labels / grad (optional): also write grad[k,n] = coeff*((label_n == k) - p[k,n]), the gradient a following logreg cost
+// sends back through this softmax (kLogregSoftmaxGrad layer_kernels.cu:154-170), while p is still in registers
 __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
-                                                       int numOut, int numCases, int chunks) {
+                                                       int numOut, int numCases, int chunks, const float* __restrict__ labels,
+                                                       float* __restrict__ grad, float coeff) {
     __shared__ float shm[16][SMF_COLS], shs[16][SMF_COLS];
     const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, col = blockIdx.x * SMF_COLS + cl, chunk = blockIdx.y;
     const bool live = col < numCases;
     float M, S;
     softmax_merge16(reinterpret_cast<const f32x2*>(part), numCases, chunks, col, live, g, cl, shm, shs, M, S);
     if (!live) return;
+    const int label = grad ? (int)labels[col] : -1;
     // a block normalises SMF_ROWS rows of its 16 columns, so that the merge above is repeated by few blocks
     const int r0 = chunk * SMF_ROWS;
     float v[SMF_ROWS / 16];
@@ -356,13 +360,18 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < SMF_ROWS / 16; i++) {
         const int r = r0 + g + 16 * i;
-        if (r < numOut) p[(size_t)r * numCases + col] = expf(v[i] - M) / S;
+        if (r < numOut) {
+            const float pv = expf(v[i] - M) / S;
+            p[(size_t)r * numCases + col] = pv;
+            if (grad) grad[(size_t)r * numCases + col] = coeff * ((label == r ? 1.f : 0.f) - pv);
+        }
     }
 }
 MCN_API size_t mcn_softmax_workspace_bytes(int numOut, int numCases) {
     return (size_t)divup(numOut, SM_ROWS) * numCases * 2 * sizeof(float);
 }
-MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
+static int softmax_impl(const float* x, float* probs, const float* labels, float* grad, float coeff, int numOut, int numCases, void* workspace,
+                        size_t workspaceBytes, void* stream) {
     MCN_REQUIRE(x && probs && numOut > 0 && numCases > 0, "softmax: bad argument");
     const int chunks = divup(numOut, SM_ROWS);
     const size_t need = mcn_softmax_workspace_bytes(numOut, numCases);
@@ -375,8 +384,16 @@ MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, 
     dim3 grid(divup(numCases, 64), chunks);
     hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
     hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, (const float*)workspace, numOut,
-                       numCases, chunks);
+                       numCases, chunks, labels, grad, coeff);
     return MCN_LAUNCH_CHECK("softmax");
+}
+MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
+    return softmax_impl(x, probs, nullptr, nullptr, 0.f, numOut, numCases, workspace, workspaceBytes, stream);
+}
+MCN_API int mcn_softmax_logreg_grad(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut, int numCases,
+                                    void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(labels && gradTarget, "softmaxLogregGrad: null pointer");
+    return softmax_impl(x, probs, labels, gradTarget, coeff, numOut, numCases, workspace, workspaceBytes, stream);
 }
 
 // ---------------------------------------------------------------- logreg cost

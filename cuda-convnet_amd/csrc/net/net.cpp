@@ -483,13 +483,26 @@ void LocalLayer::bpropWeights(float* v, int i, PassType pt) {
 // ============================================================================ SoftmaxLayer (layer.cu:582-607)
 size_t SoftmaxLayer::workspaceBytes(int maxCases) { return mcn_softmax_workspace_bytes(_outputs, maxCases); }
 
-void SoftmaxLayer::fpropActs(int, float, PassType) {
+void SoftmaxLayer::fpropActs(int, float, PassType pt) {
+    // a logreg cost on top (the DeepID nets): its gradient through this softmax needs only the probabilities and the
+    // labels, so a training pass writes it while the probabilities are still in registers (one launch and one read of
+    // the (classes, cases) matrix less on the backward chain).  Safe: fc's gradient buffer has no other writer.
+    _gradFused = false;
+    CostLayer* cost = _next.size() == 1 && _next[0]->type() == "cost.logreg" ? static_cast<CostLayer*>(_next[0]) : nullptr;
+    if (cost && pt != PASS_TEST && _net->fusion() && cost->coeff() != 0 && _prev[0]->isGradConsumer() && _prev[0]->next().size() == 1) {
+        float* labels = cost->prev()[0]->getActs();
+        chk(mcn_softmax_logreg_grad(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(),
+                                    _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax + logreg grad");
+        _gradFused = true;
+        return;
+    }
     chk(mcn_softmax(_inputs[0], _acts, _outputs, _net->numCases(), _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax");
 }
 
 void SoftmaxLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
     const bool doLogregGrad = _next.size() == 1 && _next[0]->type() == "cost.logreg";
     if (doLogregGrad) {
+        if (_gradFused && scaleTargets == 0) return;  // written during forward
         float* labels = _next[0]->prev()[0]->getActs();
         const float coeff = static_cast<CostLayer*>(_next[0])->coeff();
         chk(mcn_logreg_softmax_grad(labels, _acts, _prev[0]->getActsGrad(), _outputs, _net->numCases(), scaleTargets == 1 ? 1 : 0, coeff,
@@ -1243,8 +1256,9 @@ void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
     for (auto& l : _layers) l->reset();
     for (DataLayer* d : _dataLayers) {
         if (d->dataIdx < 0 || d->dataIdx >= (int)_curData.size()) throw NetError("data layer '" + d->name() + "': no data matrix " + std::to_string(d->dataIdx));
-        d->fpropData(_curData[d->dataIdx], pt);
+        d->setSlice(_curData[d->dataIdx]);  // every data matrix is in place before anything propagates (a fused softmax reads the labels)
     }
+    for (DataLayer* d : _dataLayers) d->fpropData(_curData[d->dataIdx], pt);
 }
 
 void ConvNet::fpropSlice(long start, long end, PassType pt) {

@@ -228,6 +228,7 @@ class SoftmaxLayer : public Layer {
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
+    bool _gradFused = false;  // this pass wrote the logreg gradient during forward
 };
 
 class EltwiseSumLayer : public Layer {
@@ -251,6 +252,7 @@ class DataLayer : public Layer {
    public:
     DataLayer(ConvNet* net, const Params& p);
     bool isGradProducer() override { return false; }
+    void setSlice(float* slice) { _acts = slice; }
     void fpropData(float* slice, PassType pt);
     void allocate(int) override {}
     int dataIdx;
@@ -543,6 +545,7 @@ class ConvNet {
     void joinExchange();
     void exchangeWorkJoined() { _exchangeWorkPending = false; }
     void setFusion(bool on) { _fusion = on; }
+    bool fusion() const { return _fusion; }
     bool profiling() const { return _profiling; }
     void profBegin(const std::string& label);
     void profEnd();

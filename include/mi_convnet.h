@@ -230,6 +230,10 @@ int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream
 size_t mcn_softmax_workspace_bytes(int numOut, int numCases);
 int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes,
                 void* stream);
+/* Softmax plus, in the same pass, what computeLogregSoftmaxGrad (layer_kernels.cu:287-308) would write for a logreg
+ * cost on top of it: gradTarget[k,n] = coeff*((labels[n] == k) - probs[k,n]) (overwrite; bit-identical to the separate call). */
+int mcn_softmax_logreg_grad(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
+                            int numCases, void* workspace, size_t workspaceBytes, void* stream);
 /* computeLogregCost (layer_kernels.cuh:39, layer_kernels.cu:216-239) + the two NVMatrix::sum() of
  * LogregCostLayer::fpropActs (layer.cu:978-979): costOut[0] += -sum(logprob), costOut[1] += numCases - sum(correct)
  * (device doubles; pass NULL to skip). */

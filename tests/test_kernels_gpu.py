@@ -760,3 +760,19 @@ def test_contrast_norm(F, img, size, N):
         d_t = dev_empty(x.shape, np.nan)
         call('mcn_response_norm_undo', dev(g), d_den, d_mean, d_out, d_t, N, F, img, img, size, scale, pw, 0.0, 1.0, None)
         close(d_t.numpy(), wt, what='cnorm undo')
+
+
+def test_softmax_with_fused_logreg_grad():
+    """mcn_softmax_logreg_grad == mcn_softmax followed by mcn_logreg_softmax_grad, bit for bit."""
+    rng = np.random.default_rng(43)
+    K, N = 1000, 96
+    x = mk(rng, K, N, scale=2.0)
+    labels = rng.integers(0, K, (1, N)).astype(np.float32)
+    nb = ws_bytes('mcn_softmax_workspace_bytes', K, N)
+    ws = capi.workspace(nb)
+    p1, p2, g1, g2 = (dev_empty((K, N), np.nan) for _ in range(4))
+    call('mcn_softmax', dev(x), p1, K, N, ws, nb, None)
+    call('mcn_logreg_softmax_grad', dev(labels), p1, g1, K, N, 0, 0.7, None)
+    call('mcn_softmax_logreg_grad', dev(x), p2, dev(labels), g2, 0.7, K, N, ws, nb, None)
+    assert np.array_equal(p1.numpy(), p2.numpy())
+    assert np.array_equal(g1.numpy(), g2.numpy())
