@@ -665,10 +665,10 @@ void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
     if (i != 0) return;
     // the cost value is off the critical path (nothing downstream reads it): side stream
     float *labels = _inputs[0], *probs = _inputs[1];
-    _net->deferSideWork([this, labels, probs] {
+    _net->deferLateWork([this, labels, probs] {
         chk(mcn_logreg_cost(labels, probs, _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
                             _net->workspaceBytes(), _net->stream()), "logreg cost");
-    }, 0);
+    });
 }
 
 void LogregCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:983-994
@@ -1236,6 +1236,27 @@ void ConvNet::finishSideWork() {
     joinGradWork();
 }
 
+// Cost VALUES nobody waits for before the batch ends: on the main stream at the very end of the pass, where it idles
+// until the side stream has finished the last gradients (early on the side stream they delayed fc6's gradients).
+void ConvNet::deferLateWork(std::function<void()> fn) {
+    if (!_gradStream || _profiling) {
+        fn();
+        return;
+    }
+    if (dataParallel()) {  // there the main stream's tail is the hand-over of the last bucket: keep the costs on the side stream
+        deferSideWork(std::move(fn), 0);
+        return;
+    }
+    _late.push_back(std::move(fn));
+}
+
+void ConvNet::runLateWork() {
+    if (_late.empty()) return;
+    auto late = std::move(_late);
+    _late.clear();
+    for (auto& fn : late) fn();
+}
+
 void ConvNet::joinGradWork() {
     if (!_deferred.empty()) {
         auto rest = std::move(_deferred);
@@ -1243,6 +1264,7 @@ void ConvNet::joinGradWork() {
         _deferredUnits = 0;
         for (auto& d : rest) d.first();  // on the main stream
     }
+    runLateWork();
     joinExchange();
     if (!_gradPending) return;
     _side.wait(_side.pushed());  // the side thread has issued everything it was given

@@ -522,6 +522,7 @@ class ConvNet {
     // between the side stream and the main stream.
     void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
     bool lastWeightLayerOfPass();
+    void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
     void finishSideWork();   // end of backward: place the remaining work, then join
     void joinGradWork();     // run whatever is still deferred on the main stream and wait for the side stream
     int numCases() const { return _numCases; }
@@ -586,6 +587,8 @@ class ConvNet {
     void* _evJoinComm = nullptr;
     long _rcclCallNs = 0, _rcclCalls = 0;  // exchange thread only (MCN_DEBUG_TIMES)
     std::vector<std::pair<std::function<void()>, int>> _deferred;
+    std::vector<std::function<void()>> _late;
+    void runLateWork();
     int _deferredUnits = 0;
     void flushSideWork(size_t count);  // first `count` deferred items -> side stream (one fork)
     DBuf _ws, _ws2;
