@@ -1338,9 +1338,13 @@ void ConvNet::gradReady(WeightLayer* l) {
                 // side stream; on the main thread the bias piece may have gone to the side stream (last layer of a pass)
                 s.onSide = t_stream == 1 || _gradPending;
                 s.onMain = t_stream != 1;
+                s.byMain = t_stream != 1;
             }
     }
-    flushBuckets(false);
+    // Only the side thread decides where a bucket ends: it sees the layers in one fixed order on every rank.  A layer
+    // finished on the main thread (the last one of the pass) is sent by the forced flush that follows it; flushing here
+    // could split the buckets differently from rank to rank, and mismatched collectives hang.
+    if (t_stream == 1) flushBuckets(false);
 }
 
 void ConvNet::flushBuckets(bool force) {
@@ -1349,7 +1353,7 @@ void ConvNet::flushBuckets(bool force) {
     size_t end = _sentUpTo;
     for (Segment& s : _segments) {
         if (s.end <= _sentUpTo) continue;
-        if (!s.ready && !force) break;
+        if (!force && (!s.ready || s.byMain)) break;  // (a layer finished by the main thread waits for the forced flush)
         end = s.end;
     }
     if (end == _sentUpTo) return;
@@ -1396,7 +1400,7 @@ void ConvNet::waitComm() {
         _commPending = false;
     }
     _sentUpTo = 0;
-    for (Segment& s : _segments) s.ready = false;
+    for (Segment& s : _segments) s.ready = s.byMain = false;
 }
 
 void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {

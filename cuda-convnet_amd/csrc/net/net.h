@@ -609,7 +609,7 @@ class ConvNet {
     int _sideUnits = 2, _wlSeen = 0, _wlPerPass = 0;
     void* _evGather = nullptr;
     void* _evComm = nullptr;
-    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; bool onSide = false, onMain = true; };
+    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; bool onSide = false, onMain = true, byMain = false; };
     std::vector<Segment> _segments;  // in arena order (reverse layer order)
     size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
     size_t _bucketFloats = 1 << 20;
