@@ -236,6 +236,10 @@ def main():
                     out['roofline']['traffic'] = rec['traffic_bytes_per_launch']
                     out['roofline']['traffic_unit'] = 'bytes/launch (PMC, corrected); algorithmic %d' % rec['algorithmic_bytes_per_launch']
             out['device_us_per_step'] = round(step_us, 1)
+            # second half of BASELINE.json's metric: filterActs (conv / local forward) as a fraction of the fp32 MFMA peak
+            conv_names = {l['name'] for l in layers if l['type'] in ('conv', 'local')}
+            out['filter_acts_frac_of_fp32_mfma_peak'] = {e['op']: e['frac'] for e in ks
+                                                         if e['op'].split('.')[0] in conv_names and '.fprop[' in e['op']}
             out['kernels'] = ks
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.workload)
