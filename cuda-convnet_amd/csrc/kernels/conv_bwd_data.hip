@@ -24,14 +24,18 @@ struct BwdDataParams {
 // A step = one (module, 16 filters) pair.  The steps a pixel needs are walked in batches of U: the loads of the
 // next batch (second register set) are in flight while the MFMAs of the current one issue, so a wave pays one memory
 // round trip per batch instead of one per step.
-template <int CV, int NQ, bool VECN, int U>
+// KS = 2 / 4: that many waves share a pixel and take every KS-th 16-filter step; their accumulators are added through LDS.  With
+// ~1.3 waves per SIMD the plain form waits on memory 46 % of the time (profiles/r01_pmc_conv2_imgacts_sq_tcp.json).
+template <int CV, int NQ, bool VECN, int U, int KS = 1>
 __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int px = blockIdx.y * 4 + wave;
-    if (px >= imgPixels) return;
+    const int pxRaw = blockIdx.y * (4 / KS) + wave / KS, ks = wave % KS;
+    const bool live = pxRaw < imgPixels;
+    if (KS == 1 && !live) return;  // (with KS == 2 every wave reaches the barrier below)
+    const int px = live ? pxRaw : imgPixels - 1;
     const int y = px / p.imgX, x = px % p.imgX;
     const int n0 = blockIdx.x * (64 * NQ);
     const int ctiles = (fc + 16 * CV - 1) / (16 * CV);
@@ -59,8 +63,9 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const float* hb = p.hidActs + (size_t)grp * fpg * M * p.N + n0 + 4 * j;
     const float* wb = p.filters + (size_t)grp * fpg + 4 * kk;
 
-    const int total = max(0, endY - startY) * max(0, endX - startX) * (fpg / 16);
-    int lmy = startY, lmx = startX, lf16 = 0;  // the next step to load
+    const int f16Steps = (fpg / 16 - ks + KS - 1) / KS;  // this wave's 16-filter steps per module
+    const int total = live ? max(0, endY - startY) * max(0, endX - startX) * f16Steps : 0;
+    int lmy = startY, lmx = startX, lf16 = 16 * ks;  // the next step to load
     auto load = [&](f32x4(&a)[U][CV], f32x4(&b)[U][4][NQ], int count) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -85,9 +90,9 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
                         }
                     }
                 }
-                lf16 += 16;
+                lf16 += 16 * KS;
                 if (lf16 >= fpg) {
-                    lf16 = 0;
+                    lf16 = 16 * ks;
                     if (++lmx == endX) { lmx = startX; lmy++; }
                 }
             }
@@ -133,6 +138,24 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
         }
     }
 
+    if constexpr (KS > 1) {
+        __shared__ f32x4 red[4 / KS][KS - 1][CV * NQ * 4][64];
+        if (ks > 0) {
+#pragma unroll
+            for (int v = 0; v < CV; v++)
+#pragma unroll
+                for (int t = 0; t < NQ * 4; t++) red[wave / KS][ks - 1][v * NQ * 4 + t][lane] = acc[v][t];
+        }
+        __syncthreads();
+        if (ks > 0 || !live) return;
+#pragma unroll
+        for (int o = 0; o < KS - 1; o++)  // fixed order
+#pragma unroll
+            for (int v = 0; v < CV; v++)
+#pragma unroll
+                for (int t = 0; t < NQ * 4; t++) acc[v][t] += red[wave / KS][o][v * NQ * 4 + t][lane];
+    }
+
     // D row 4*kk + r of tile v <-> channel c0 + 16v + 4kk + r ; col j of MFMA t <-> image n0+64q+4j+t
 #pragma unroll
     for (int v = 0; v < CV; v++) {
@@ -164,17 +187,24 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
 }
 
 template <int CV, int NQ>
-static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipelined, hipStream_t s) {
+static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipelined, int ksplit, hipStream_t s) {
     constexpr int U = CV + 4 * NQ <= 6 ? 4 : 2;  // steps per register set: (CV + 4 NQ) * 4 VGPRs each, two sets
     if (vecn && pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U>), grid, dim3(256), 0, s, p);
+    else if (vecn && ksplit) {
+        if constexpr (CV == 1 && NQ == 1) {
+            grid.y = divup(p.imgY * p.imgX, 4 / ksplit);  // 4 / KS pixels per block
+            if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 1, 4>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_img_acts<1, 1, true, 1, 2>), grid, dim3(256), 0, s, p);
+        }
+    }
     else if (vecn) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_img_acts<CV, NQ, false, 1>), grid, dim3(256), 0, s, p);
 }
 
 template <int CV>
-static void launch_bd1(const BwdDataParams& p, int nq, dim3 grid, bool vecn, bool pipelined, hipStream_t s) {
-    if (nq == 2) launch_bd2<CV, 2>(p, grid, vecn, pipelined, s);
-    else launch_bd2<CV, 1>(p, grid, vecn, pipelined, s);
+static void launch_bd1(const BwdDataParams& p, int nq, dim3 grid, bool vecn, bool pipelined, int ksplit, hipStream_t s) {
+    if (nq == 2) launch_bd2<CV, 2>(p, grid, vecn, pipelined, 0, s);
+    else launch_bd2<CV, 1>(p, grid, vecn, pipelined, ksplit, s);
 }
 
 static int img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int imgY, int imgX,
@@ -213,11 +243,15 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     // batched, prefetched steps (measured: local3 18.8 -> 15.6 us; long step chains and shared-weight layers do not gain)
     const int maxSteps = divup(fs, stride) * divup(fs, stride) * (F / groups / 16);
     const bool pipelined = !conv && waves(CV, NQ) < 3 * 1024 && maxSteps <= 32;
+    // under two waves per SIMD: two waves per pixel (measured: conv2 22.2 -> 16.7 us, local4 9.6 -> 7.0 us; preferred over
+    // the prefetched form where both apply)
+    int ksplit = vecn && CV == 1 && NQ == 1 && (F / groups / 16) >= 2 && waves(CV, NQ) < 2048 && divup(imgPixels, 2) <= 65535 ? 2 : 0;
+    if (ksplit && (F / groups / 16) >= 4 && waves(CV, NQ) < 1024 && imgPixels <= 65535) ksplit = 4;  // (local4: 7.0 -> 6.4 us)
     switch (CV) {
-        case 4: launch_bd1<4>(p, NQ, grid, vecn, pipelined, s); break;
-        case 3: launch_bd1<3>(p, NQ, grid, vecn, pipelined, s); break;
-        case 2: launch_bd1<2>(p, NQ, grid, vecn, pipelined, s); break;
-        default: launch_bd1<1>(p, NQ, grid, vecn, pipelined, s); break;
+        case 4: launch_bd1<4>(p, NQ, grid, vecn, pipelined, 0, s); break;
+        case 3: launch_bd1<3>(p, NQ, grid, vecn, pipelined, 0, s); break;
+        case 2: launch_bd1<2>(p, NQ, grid, vecn, pipelined, 0, s); break;
+        default: launch_bd1<1>(p, NQ, grid, vecn, pipelined && !ksplit, ksplit, s); break;
     }
     return MCN_LAUNCH_CHECK("imgActs");
 }
