@@ -11,6 +11,7 @@
 // images with one 16-byte load and uses component t in step t.  One 4-wave block owns
 // 16*KV weight rows x 16*FV filters for one module chunk: its waves take the chunk's
 // modules round-robin and their accumulators are summed through LDS in a fixed order.
+#include <mutex>
 #include "common.h"
 
 struct BwdWParams {
@@ -512,7 +513,7 @@ MCN_API size_t mcn_conv_weight_acts_reduced_workspace_bytes(int numImgColors, in
     return chunks * K * numFilters * sizeof(float);
 }
 
-MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, float* grad, void* workspace,
+static int conv_weight_acts_reduced_impl(const float* images, const float* hidActs, float* grad, void* workspace,
                                          size_t workspaceBytes, int numImages, int imgStride, int imgSizeY,
                                          int imgSizeX, int numImgColors, int numFilters, int filterSize,
                                          int numModulesY, int numModulesX, int paddingStart, int moduleStride,
@@ -566,4 +567,68 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
     hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, grad, chunks, cols, scaleTargets);
     return MCN_LAUNCH_CHECK("convWeightActsReduced");
+}
+
+MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, float* grad, void* workspace,
+                                         size_t workspaceBytes, int numImages, int imgStride, int imgSizeY,
+                                         int imgSizeX, int numImgColors, int numFilters, int filterSize,
+                                         int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                         int numGroups, float scaleTargets, float scaleOutput, void* stream) {
+    return conv_weight_acts_reduced_impl(images, hidActs, grad, workspace, workspaceBytes, numImages, imgStride, imgSizeY, imgSizeX,
+                                         numImgColors, numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride,
+                                         numGroups, scaleTargets, scaleOutput, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same call for callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the module-chunk partials go to a file-scope device array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy of the array at its own address until the process ends; the address is looked up
+// once per device (hipGetSymbolAddress, at the first call with that device current) and only that pointer is ever
+// handed to kernels -- the array's name is a host-side stand-in, not a device address.
+// Nothing has to start at zero: both partial kernels write every (chunk, k, f) slot the reduce pass reads, so the
+// contents the previous call left are simply overwritten.  Calls that overlap on one GPU race on the array.
+#define MCN_WA_SCRATCH_BYTES (4u << 20)
+#define MCN_MAX_DEVICES 64
+static __device__ __align__(256) float scratch[MCN_WA_SCRATCH_BYTES / sizeof(float)];
+static std::mutex g_scratchMutex;
+static float* g_scratchPtr[MCN_MAX_DEVICES];  // per device; null = not looked up yet
+
+static int scratch_for_current_device(float** out) {
+    int dev = -1;
+    int rc = mcn_check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    MCN_REQUIRE(dev >= 0 && dev < MCN_MAX_DEVICES, "convWeightActsReducedStatic: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_scratchMutex);
+    if (!g_scratchPtr[dev]) {
+        void* ptr = nullptr;
+        rc = mcn_check_hip(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "hipGetSymbolAddress(scratch)");
+        if (rc) return rc;
+        MCN_REQUIRE(ptr != nullptr, "convWeightActsReducedStatic: no device address for the scratch array");
+        g_scratchPtr[dev] = (float*)ptr;
+    }
+    *out = g_scratchPtr[dev];
+    return MCN_OK;
+}
+
+MCN_API size_t mcn_conv_weight_acts_reduced_static_max_bytes(void) { return MCN_WA_SCRATCH_BYTES; }
+
+MCN_API int mcn_conv_weight_acts_reduced_static(const float* images, const float* hidActs, float* grad, int numImages,
+                                                int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                                int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                                                int moduleStride, int numGroups, float scaleTargets, float scaleOutput,
+                                                void* stream) {
+    MCN_REQUIRE(numImgColors > 0 && numFilters > 0 && filterSize > 0 && numModulesY > 0 && numModulesX > 0 && numGroups > 0,
+                "convWeightActsReducedStatic: non-positive dimension");
+    const size_t need = mcn_conv_weight_acts_reduced_workspace_bytes(numImgColors, numFilters, filterSize, numModulesY, numModulesX, numGroups);
+    if (need > MCN_WA_SCRATCH_BYTES) {
+        mcn_set_error("convWeightActsReducedStatic: this shape needs %zu bytes of partials, the static scratch holds %u "
+                      "(use mcn_conv_weight_acts_reduced with a caller workspace)", need, (unsigned)MCN_WA_SCRATCH_BYTES);
+        return MCN_EWORKSPACE;
+    }
+    float* ptr = nullptr;
+    int rc = scratch_for_current_device(&ptr);
+    if (rc) return rc;
+    return conv_weight_acts_reduced_impl(images, hidActs, grad, ptr, MCN_WA_SCRATCH_BYTES, numImages, imgStride, imgSizeY, imgSizeX,
+                                         numImgColors, numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride,
+                                         numGroups, scaleTargets, scaleOutput, stream);
 }

@@ -143,6 +143,19 @@ int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, floa
                                  int paddingStart, int moduleStride, int numGroups,
                                  float scaleTargets, float scaleOutput, void* stream);
 
+/* No counterpart in the reference.  mcn_conv_weight_acts_reduced for callers that cannot allocate device memory or
+ * bring a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+ * module-chunk partials live in a static device array of mcn_conv_weight_acts_reduced_static_max_bytes() = 4 MiB
+ * that each GPU the library runs on holds until the process ends.  Shapes whose partials need more return
+ * MCN_EWORKSPACE (every DeepID / DeepID2+ / CIFAR conv layer at minibatch 128 fits).  Calls no hipMalloc / hipFree.
+ * All calls on one GPU share the array: calls that overlap on one GPU (two streams) race. */
+size_t mcn_conv_weight_acts_reduced_static_max_bytes(void);
+int mcn_conv_weight_acts_reduced_static(const float* images, const float* hidActs, float* grad,
+                                        int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                        int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                        int paddingStart, int moduleStride, int numGroups,
+                                        float scaleTargets, float scaleOutput, void* stream);
+
 /* ---- conv_util.cuh ---------------------------------------------------------------------- */
 /* convLocalPool<MaxPooler|AvgPooler> (conv_util.cuh:327-517). mode 0 = max, 1 = avg (clipped window). */
 int mcn_local_pool(const float* images, float* target, int numImages, int numFilters, int imgSizeY,
