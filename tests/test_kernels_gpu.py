@@ -26,6 +26,7 @@ GEOMS = {
     'conv2': (26, 26, 16, 32, 3, 24, 24, 0, 1, 1, True),
     'conv2_plus': (26, 26, 32, 128, 3, 24, 24, 0, 1, 1, True),
     'local3_plus': (12, 12, 128, 128, 3, 10, 10, 0, 1, 1, False),
+    'local4_plus': (5, 5, 128, 128, 2, 4, 4, 0, 1, 1, False),
     'conv_f48': (20, 20, 8, 48, 3, 18, 18, 0, 1, 1, True),
     'conv_f64_pad': (24, 24, 4, 64, 5, 24, 24, -2, 1, 1, True),
     'conv2_39x31': (18, 14, 16, 32, 3, 16, 12, 0, 1, 1, True),
@@ -139,7 +140,8 @@ def test_filter_acts_rejects_bad_args():
 
 # ----------------------------------------------------------------------------------- imgActs
 @pytest.mark.parametrize('name', ['conv2', 'conv2_39x31', 'local3', 'local3_39x31', 'local4', 'local4_39x31', 'conv1_39x31',
-                                  'cifar_conv2', 'cifar_conv3', 'stride2_pad', 'groups2', 'local_groups2_pad', 'odd_k'])
+                                  'cifar_conv2', 'cifar_conv3', 'stride2_pad', 'groups2', 'local_groups2_pad', 'odd_k',
+                                  'conv1_plus', 'conv2_plus', 'local3_plus', 'local4_plus'])
 def test_img_acts_shapes(name):
     g = GEOMS[name]
     imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
@@ -175,7 +177,8 @@ def test_img_acts_ragged_accumulate(name, N):
 @pytest.mark.parametrize('name,ps', [('conv1_55', 1), ('conv1_39x31', 1), ('conv1_39x31', 0), ('conv2', 1), ('conv2_39x31', 4),
                                      ('cifar_conv1', 32), ('cifar_conv3', 0), ('stride2_pad', 1), ('groups2', 8), ('odd_k', 1),
                                      ('local3', 1), ('local3_39x31', 1), ('local4', 1), ('local4_39x31', 1),
-                                     ('local_groups2_pad', 1)])
+                                     ('local_groups2_pad', 1),
+                                     ('conv1_plus', 1), ('conv2_plus', 1), ('local3_plus', 1), ('local4_plus', 1)])
 def test_weight_acts_shapes(name, ps):
     g = GEOMS[name]
     imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
@@ -215,7 +218,8 @@ def test_weight_acts_ragged_momentum(name, N):
     close(d_out.numpy(), want, what='%s N=%d' % (name, N))
 
 
-@pytest.mark.parametrize('name', ['conv1_55', 'conv1_39x31', 'conv2', 'conv2_39x31', 'cifar_conv1', 'cifar_conv3'])
+@pytest.mark.parametrize('name', ['conv1_55', 'conv1_39x31', 'conv2', 'conv2_39x31', 'cifar_conv1', 'cifar_conv3',
+                                  'conv1_plus', 'conv2_plus'])
 @pytest.mark.parametrize('sT', [0.0, 1.0])
 def test_conv_weight_acts_reduced(name, sT):
     """ConvLayer::bpropWeights in one call == weightActs(partialSum) + addSum over module chunks."""

@@ -1,0 +1,114 @@
+"""Whole-net parity at the per-kernel tolerance: for every BASELINE preset
+
+  * every layer's forward activities, read back through startFeatureWriter (worker.cu:191-214), against the
+    whole-net CPU oracle on the same seeded minibatch:   max|a-b| <= 1e-4*max|b| + 1e-6 per layer;
+  * every weight / bias increment after ONE training step (inc = (eps/N)*gradient, momentum not yet engaged, so
+    this is the back-propagated gradient of every layer):   max|a-b| <= 1e-4*max|b| + 1e-9 per matrix;
+  * the step scheduled over two streams / two submitting threads must give bit-identical weights to the same step
+    issued on one stream (MCN_NO_GRAD_STREAM=1): every reduction has a fixed order, so any difference is a missing
+    dependency between the streams.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import ccn_loader
+
+ccn_loader.load()
+from cuda_convnet_amd import layer  # noqa: E402
+from oracle.net import OracleNet  # noqa: E402
+from test_net_gpu import Native, preset  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PRESET_NAMES = ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm']
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b))), float(np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_every_layer_forward_matches_oracle(name):
+    dp, Lg = preset(name, 128)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    onet = OracleNet(Lc, 128)
+    onet.fprop(data, 1)  # PASS_TEST, like the feature writer
+    checked = 0
+    with Native(Lg) as lib:
+        for idx, l in enumerate(Lg):
+            if l['type'] == 'data' or l['type'].startswith('cost.') or l['outputs'] <= 0:
+                continue
+            ftrs = np.full((128, l['outputs']), np.nan, np.float32)
+            lib.startFeatureWriter(list(data) + [ftrs], idx)
+            lib.finishBatch()
+            want = onet.layers[idx].acts.T
+            assert np.all(np.isfinite(ftrs)), l['name']
+            err, mx = rel_err(ftrs, want)
+            assert err <= 1e-4 * mx + 1e-6, 'layer %s (%s): max abs err %.3e > %.3e' % (l['name'], l['type'], err, 1e-4 * mx + 1e-6)
+            checked += 1
+    assert checked >= 8
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_one_step_gradients_match_oracle(name):
+    dp, Lg = preset(name, 128)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    onet = OracleNet(Lc, 128)
+    want_cost, _ = onet.run_batch(data)
+    onet.sync_with_host()
+    with Native(Lg) as lib:
+        lib.startBatch(data, 0)
+        got_cost, n = lib.finishBatch()
+        lib.syncWithHost()
+    assert n == 128
+    for k, v in want_cost.items():
+        assert abs(got_cost[k][0] - v[0]) <= 1e-4 * abs(v[0]) + 1e-5, (k, got_cost[k], v)
+        assert got_cost[k][1:] == v[1:], (k, got_cost[k], v)
+    for lg, lc in zip(Lg, Lc):
+        if 'weights' not in lg:
+            continue
+        pairs = [('weightsInc[%d]' % i, a, b) for i, (a, b) in enumerate(zip(lg['weightsInc'], lc['weightsInc']))]
+        pairs.append(('biasesInc', lg['biasesInc'], lc['biasesInc']))
+        for nm, a, b in pairs:
+            err, mx = rel_err(a, b)
+            assert mx > 0, '%s %s: the oracle never updated it' % (lg['name'], nm)
+            assert err <= 1e-4 * mx + 1e-9, '%s %s: max abs err %.3e > %.3e' % (lg['name'], nm, err, 1e-4 * mx + 1e-9)
+
+
+def train3(name, env):
+    dp, L = preset(name, 384)
+    data = dp.get_next_batch()[2]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with Native(L) as lib:  # the environment is read when the model's device thread starts
+            lib.startBatch(data, 0)
+            costs = lib.finishBatch()
+            lib.syncWithHost()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return L, costs
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_two_streams_equal_one_stream_bitwise(name):
+    La, ca = train3(name, {})
+    Lb, cb = train3(name, {'MCN_NO_GRAD_STREAM': '1'})
+    assert ca == cb, (ca, cb)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between the two-stream and the one-stream schedule' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between the two-stream and the one-stream schedule' % (la['name'], key)
