@@ -367,6 +367,104 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
         }
     }
 }
+// The same stage 2 with 16-byte accesses: a block owns 32 columns (8 lanes x 4) x SMF4_ROWS rows, so that every wave
+// instruction touches whole 128-byte lines of x / p / grad (the scalar form above moves 64 bytes per row and lane group).
+// Merge: lane group g (of 32) merges chunks g, g+32, ... of its 4 columns, the 32 groups are combined through LDS by 32
+// threads (one column each, fixed order) and M, S are broadcast through LDS.
+#define SMF4_ROWS 128
+__global__ __launch_bounds__(256) void k_softmax_final4(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
+                                                        int numOut, int numCases, int chunks, const float* __restrict__ labels,
+                                                        float* __restrict__ grad, float coeff) {
+    __shared__ float shm[32][33], shs[32][33], shM[32], shS[32];
+    const int cl = threadIdx.x & 7, g = threadIdx.x >> 3, col = blockIdx.x * 32 + 4 * cl;
+    const bool live = col < numCases;  // numCases % 4 == 0
+    // this thread's x values first: their latency hides behind the merge of the partials
+    const int r0 = blockIdx.y * SMF4_ROWS;
+    f32x4 v[SMF4_ROWS / 32];
+#pragma unroll
+    for (int i = 0; i < SMF4_ROWS / 32; i++) {
+        const int r = r0 + g + 32 * i;
+        v[i] = (live && r < numOut) ? *reinterpret_cast<const f32x4*>(x + (size_t)r * numCases + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // chunk partials of 4 consecutive columns = 8 consecutive floats (max, sum interleaved)
+    f32x4 lm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, ls = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = g; c0 < chunks; c0 += 32 * 4) {
+        f32x4 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + 32 * u;
+            const bool ok = live && c < chunks;
+            const float* src = part + ((size_t)c * numCases + col) * 2;
+            v0[u] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){-INFINITY, 0.f, -INFINITY, 0.f};
+            v1[u] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : (f32x4){-INFINITY, 0.f, -INFINITY, 0.f};
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            float bm = lm[t];
+#pragma unroll
+            for (int u = 0; u < 4; u++) bm = fmaxf(bm, t < 2 ? v0[u][2 * t] : v1[u][2 * (t - 2)]);
+            float bs = lm[t] == -INFINITY ? 0.f : ls[t] * expf(lm[t] - bm);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float m = t < 2 ? v0[u][2 * t] : v1[u][2 * (t - 2)], sv = t < 2 ? v0[u][2 * t + 1] : v1[u][2 * (t - 2) + 1];
+                bs += m == -INFINITY ? 0.f : sv * expf(m - bm);
+            }
+            lm[t] = bm;
+            ls[t] = bs;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        shm[g][4 * cl + t] = lm[t];
+        shs[g][4 * cl + t] = ls[t];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int c = threadIdx.x;
+        float M = -INFINITY, S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k++) M = fmaxf(M, shm[k][c]);
+#pragma unroll
+        for (int k = 0; k < 32; k++) S += shm[k][c] == -INFINITY ? 0.f : shs[k][c] * expf(shm[k][c] - M);
+        shM[c] = M;
+        shS[c] = S;
+    }
+    __syncthreads();
+    if (!live) return;
+    f32x4 M4, S4;
+    int lab[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        M4[t] = shM[4 * cl + t];
+        S4[t] = shS[4 * cl + t];
+        lab[t] = grad ? (int)labels[col + t] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < SMF4_ROWS / 32; i++) {
+        const int r = r0 + g + 32 * i;
+        if (r < numOut) {
+            f32x4 pv, gv;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                pv[t] = expf(v[i][t] - M4[t]) / S4[t];
+                gv[t] = coeff * ((lab[t] == r ? 1.f : 0.f) - pv[t]);
+            }
+            *reinterpret_cast<f32x4*>(p + (size_t)r * numCases + col) = pv;
+            if (grad) *reinterpret_cast<f32x4*>(grad + (size_t)r * numCases + col) = gv;
+        }
+    }
+}
+
+static int softmax_final_launch(const float* x, float* probs, const float* part, int numOut, int numCases, int chunks, const float* labels,
+                                float* grad, float coeff, hipStream_t s) {
+    if (numCases % 4 == 0 && al16(x) && al16(probs) && al16(part) && (!grad || al16(grad)) && divup(numOut, SMF4_ROWS) <= 65535)
+        hipLaunchKernelGGL(k_softmax_final4, dim3(divup(numCases, 32), divup(numOut, SMF4_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
+                           numCases, chunks, labels, grad, coeff);
+    else
+        hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
+                           numCases, chunks, labels, grad, coeff);
+    return MCN_LAUNCH_CHECK("softmax");
+}
 MCN_API size_t mcn_softmax_workspace_bytes(int numOut, int numCases) {
     return (size_t)divup(numOut, SM_ROWS) * numCases * 2 * sizeof(float);
 }
@@ -383,9 +481,19 @@ static int softmax_impl(const float* x, float* probs, const float* labels, float
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(divup(numCases, 64), chunks);
     hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
-    hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, (const float*)workspace, numOut,
-                       numCases, chunks, labels, grad, coeff);
-    return MCN_LAUNCH_CHECK("softmax");
+    return softmax_final_launch(x, probs, (const float*)workspace, numOut, numCases, chunks, labels, grad, coeff, s);
+}
+// stage 2 alone, from partials the classifier layer's forward product left (mcn_gemm_bias_neuron_softmax_part)
+MCN_API int mcn_softmax_from_part(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
+                                  int numCases, const void* part, size_t partBytes, void* stream) {
+    MCN_REQUIRE(x && probs && part && numOut > 0 && numCases > 0, "softmaxFromPart: bad argument");
+    MCN_REQUIRE((labels != nullptr) == (gradTarget != nullptr), "softmaxFromPart: labels and gradTarget go together");
+    const int chunks = divup(numOut, SM_ROWS);
+    if (partBytes < mcn_softmax_workspace_bytes(numOut, numCases)) {
+        mcn_set_error("softmaxFromPart: partial buffer %zu < %zu bytes", partBytes, mcn_softmax_workspace_bytes(numOut, numCases));
+        return MCN_EWORKSPACE;
+    }
+    return softmax_final_launch(x, probs, (const float*)part, numOut, numCases, chunks, labels, gradTarget, coeff, (hipStream_t)stream);
 }
 MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
     return softmax_impl(x, probs, nullptr, nullptr, 0.f, numOut, numCases, workspace, workspaceBytes, stream);

@@ -1,0 +1,14 @@
+// LDS-staged / row-split GEMM forms for the classifier-layer shapes (fc_gemm.hip); gemm.hip dispatches to them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+bool fc_nn_lds_usable(const float* A, const float* B, const float* C, int M, int N, int K);
+bool fc_nt_lds_usable(const float* A, const float* B, const float* C, int M, int N, int K);
+bool fc_tn_split_usable(const float* A, const float* B, const float* C, int M, int N, int K);
+size_t fc_tn_split_workspace_bytes(int M, int N, int K);
+int fc_nn_lds_launch(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, float alpha, float beta,
+                     int neuron, float na, float nb, float* smPart, hipStream_t s);
+int fc_nt_lds_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, hipStream_t s);
+int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, void* workspace,
+                       size_t workspaceBytes, hipStream_t s);

@@ -1,0 +1,496 @@
+// FC-layer GEMMs for the shapes of the classifier layer (fc6: 4213 / 10575 outputs x 160 / 512 inputs, 128 cases):
+// LDS-staged forms of the three products of FCLayer (layer.cu:355-384, NVMatrix::addProduct nvmatrix.cu:189-239).
+//
+// The general kernels of gemm.hip give every wave its own operand stream from global memory, which for a tall W
+// (thousands of rows) against a small X (inputs x cases, 80 KB) means that every wave fetches X again: PMC showed
+// 37.6 MB of traffic for 12.3 MB of data on the backward-data product and the launches ran at 12-18 % of the MFMA
+// rate.  Here
+//   * forward  Y[O x n] = W[O x I] X[I x n] (+ bias, neuron)  and
+//     weights  dW[O x I] = a dY[O x n] X[I x n]^T + b dW
+//     stage X ONCE per workgroup in LDS (conflict-free for ds_read_b128: see the layouts below); a wave owns 16 rows
+//     of W / dY, whose fragments are all requested before the first MFMA, and every X fragment it needs comes from LDS;
+//   * backward-data dX[I x n] = W^T dY (reduction over the O = thousands of rows) splits the rows over the grid, with
+//     output tiles of 80 x 64 so that the partial slabs stay small (64 x 80 KB instead of the operands being re-read
+//     per 64 x 64 tile), and a fixed-order second pass adds the slabs.
+// The forward kernel can also leave, per 64-row block, the per-case (max, sum exp(x - max)) of its rows: stage 1 of the
+// softmax that follows the classifier layer (SoftmaxLayer::fpropActs layer.cu:585-595), which then needs no pass of
+// its own over the (classes x cases) matrix.
+// v_mfma_f32_16x16x4_f32 throughout (exact fp32), operand index permutations as in gemm.hip.
+#include <algorithm>
+#include "common.h"
+#include "fc_gemm.h"
+
+struct FcParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    float* smPart;   // NN only: (rowBlocks, N, 2) softmax stage-1 partials, or null
+    float* part;     // TN only: split-K partial slabs
+    int M, N, K;
+    int kChunk, splits;
+    int neuron;
+    float alpha, beta, na, nb;
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+#define F4ZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
+
+// ---------------------------------------------------------------------------------------------
+// NN, tall A.  Workgroup = 4 waves = 64 rows of A x one 128-column tile of B/C.  K is walked in chunks of 16*S rows of B
+// (S = 10: K = 160 in one chunk, 80 KB of LDS).  LDS image of the chunk: plain [k][128] floats; a fragment read is
+// lane (j, kk) -> row 16s + 4kk + e, columns 4j..4j+3 (+64): within each 16-lane group of a ds_read_b128 the lanes of one
+// kk cover 256 contiguous bytes and rows are 512 B apart, i.e. all 64 banks once -- conflict-free without padding.
+// ---------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(256) void k_fc_nn_lds(const FcParams p) {
+    extern __shared__ f32x4 lds4[];
+    float* lds = reinterpret_cast<float*>(lds4);
+    constexpr int KC = 16 * S, NLD = KC * 32 / 256;  // staging loads (16 B) per thread and chunk
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int m0 = blockIdx.x * 64 + 16 * wave, n0 = blockIdx.y * 128;
+    const float* arow = p.A + (size_t)min(m0 + j, p.M - 1) * p.K + 4 * kk;
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) acc[t] = F4ZERO;
+    float biasv[4];  // requested first: the latency hides behind the whole k loop instead of stalling the epilogue
+#pragma unroll
+    for (int r = 0; r < 4; r++) biasv[r] = p.bias ? p.bias[min(m0 + 4 * kk + r, p.M - 1)] : 0.f;
+
+    for (int kc0 = 0; kc0 < p.K; kc0 += KC) {
+        // this wave's A fragments of the chunk and this thread's share of the B chunk: all requested at once
+        f32x4 a[S], st[NLD];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int k = kc0 + 16 * s + 4 * kk;
+            a[s] = k < p.K ? ldg4(arow + kc0 + 16 * s) : F4ZERO;  // K % 4 == 0
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = threadIdx.x + 256 * i, row = idx >> 5, c4 = idx & 31;
+            const int k = kc0 + row, n = n0 + 4 * c4;
+            st[i] = (k < p.K && n < p.N) ? ldg4(p.B + (size_t)k * p.N + n) : F4ZERO;  // N % 4 == 0
+        }
+        if (kc0 > 0) __syncthreads();  // the previous chunk's fragments have been read
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = threadIdx.x + 256 * i;
+            *reinterpret_cast<f32x4*>(lds + 4 * idx) = st[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float* br = lds + (16 * s + 4 * kk + e) * 128 + 4 * j;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(br), b1 = *reinterpret_cast<const f32x4*>(br + 64);
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[t] = mfma16(a[s][e], b0[t], acc[t]);
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[4 + t] = mfma16(a[s][e], b1[t], acc[4 + t]);
+            }
+    }
+
+    // D row 4kk + r <-> row m0 + 4kk + r ; tile (q, t), lane j <-> column n0 + 64q + 4j + t
+    f32x4 v[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + 4 * kk + r, n = n0 + 64 * q + 4 * j;
+            f32x4 o = p.alpha * (f32x4){acc[4 * q][r], acc[4 * q + 1][r], acc[4 * q + 2][r], acc[4 * q + 3][r]};
+            if (m < p.M && n < p.N) {
+                float* c = p.C + (size_t)m * p.N + n;
+                if (p.beta != 0.f) o += p.beta * ldg4(c);
+                o += biasv[r];
+                if (p.neuron != MCN_NEURON_IDENT) {
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o[t] = neuron_apply(p.neuron, o[t], p.na, p.nb);
+                }
+                *reinterpret_cast<f32x4*>(c) = o;
+            } else {
+                o = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // not a row / column of C: leaves the softmax partial alone
+            }
+            v[q][r] = o;
+        }
+    if (!p.smPart) return;
+
+    // softmax stage 1 over this block's 64 rows: per column max, then sum exp(x - max); fixed order
+    __syncthreads();  // everyone is done with the B chunk
+    float* shm = lds;             // [4 waves][128]
+    float* shs = lds + 4 * 128;   // [4 waves][128]
+    f32x4 mx[2], sm[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        f32x4 m4 = v[q][0];
+#pragma unroll
+        for (int r = 1; r < 4; r++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) m4[t] = fmaxf(m4[t], v[q][r][t]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            m4[t] = fmaxf(m4[t], __shfl_xor(m4[t], 16));
+            m4[t] = fmaxf(m4[t], __shfl_xor(m4[t], 32));
+        }
+        if (kk == 0) *reinterpret_cast<f32x4*>(shm + wave * 128 + 64 * q + 4 * j) = m4;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const float* c = shm + 64 * q + 4 * j;
+        f32x4 m4 = ldg4(c);
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            const f32x4 o = ldg4(c + 128 * w);
+#pragma unroll
+            for (int t = 0; t < 4; t++) m4[t] = fmaxf(m4[t], o[t]);
+        }
+        mx[q] = m4;
+        f32x4 s4 = F4ZERO;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) s4[t] += v[q][r][t] == -INFINITY ? 0.f : expf(v[q][r][t] - m4[t]);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            s4[t] += __shfl_xor(s4[t], 16);
+            s4[t] += __shfl_xor(s4[t], 32);
+        }
+        sm[q] = s4;
+        if (kk == 0) *reinterpret_cast<f32x4*>(shs + wave * 128 + 64 * q + 4 * j) = s4;
+    }
+    __syncthreads();
+    if (wave == 0 && kk == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float* c = shs + 64 * q + 4 * j;
+            const f32x4 s4 = (ldg4(c) + ldg4(c + 128)) + (ldg4(c + 256) + ldg4(c + 384));
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int n = n0 + 64 * q + 4 * j + t;
+                if (n < p.N) {
+                    float* o = p.smPart + ((size_t)blockIdx.x * p.N + n) * 2;
+                    o[0] = mx[q][t];
+                    o[1] = s4[t];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT, tall A:  C[M x I] = alpha A[M x K] B[I x K]^T + beta C  (dW = dY X^T; K = cases).  Workgroup = 4 waves = 64 rows of
+// A x one tile of NT*16 columns (rows of B).  The B tile is staged in LDS as [i][32 x 16-byte chunks] (K chunk of 128),
+// chunk c of row i at slot c ^ h(i), h(i) = ((i >> 2) ^ (i << 2)) & 15: a fragment read is lane (j, kk) -> row i(j),
+// chunk 4s + kk, and h spreads the 16 rows of a tile over the 16 bank groups for both column orders used below.
+// Column order: tiles come in groups of four, tile u of group g <-> columns 64g + 4j + u, so that a lane holds four
+// consecutive columns of a row and the epilogue moves 16 bytes per lane; left-over tiles <-> columns base + 16u + j.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nt_swz(int i) { return ((i >> 2) ^ (i << 2)) & 15; }
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_fc_nt_lds(const FcParams p) {
+    extern __shared__ f32x4 lds4[];
+    float* lds = reinterpret_cast<float*>(lds4);
+    constexpr int NC = 16 * NT, G = NT / 4, NLD = NC * 32 / 256;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int m0 = blockIdx.x * 64 + 16 * wave, i0 = blockIdx.y * NC;
+    const float* arow = p.A + (size_t)min(m0 + j, p.M - 1) * p.K + 4 * kk;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = F4ZERO;
+    int irow[NT], isw[NT];  // LDS row of this lane's B fragment per tile, and its swizzle
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        irow[t] = t < 4 * G ? 64 * (t / 4) + 4 * j + (t % 4) : 64 * G + 16 * (t - 4 * G) + j;
+        isw[t] = nt_swz(irow[t]);
+    }
+
+    // beta != 0 (momentum: dW = mom * dW + ...): the C tile is requested before the k loop, not after it
+    f32x4 cpre[G > 0 ? G : 1][4];
+    float cpre1[NT - 4 * G > 0 ? NT - 4 * G : 1][4];
+    if (p.beta != 0.f) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float* crow = p.C + (size_t)min(m0 + 4 * kk + r, p.M - 1) * p.N + i0;
+#pragma unroll
+            for (int g = 0; g < G; g++) cpre[g][r] = i0 + 64 * g + 4 * j < p.N ? ldg4(crow + 64 * g + 4 * j) : F4ZERO;
+#pragma unroll
+            for (int t = 4 * G; t < NT; t++) cpre1[t - 4 * G][r] = i0 + irow[t] < p.N ? crow[irow[t]] : 0.f;
+        }
+    }
+
+    for (int kc0 = 0; kc0 < p.K; kc0 += 128) {
+        f32x4 a[8], st[NLD];
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int k = kc0 + 16 * s + 4 * kk;
+            a[s] = k < p.K ? ldg4(arow + kc0 + 16 * s) : F4ZERO;  // K % 4 == 0
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = threadIdx.x + 256 * i, row = idx >> 5, c = idx & 31;
+            const int gi = i0 + row, k = kc0 + 4 * c;
+            st[i] = (gi < p.N && k < p.K) ? ldg4(p.B + (size_t)gi * p.K + k) : F4ZERO;
+        }
+        if (kc0 > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const int idx = threadIdx.x + 256 * i, row = idx >> 5, c = idx & 31;
+            *reinterpret_cast<f32x4*>(lds + (row * 32 + (c ^ nt_swz(row))) * 4) = st[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            f32x4 b[NT];
+#pragma unroll
+            for (int t = 0; t < NT; t++) b[t] = *reinterpret_cast<const f32x4*>(lds + (irow[t] * 32 + ((4 * s + kk) ^ isw[t])) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[t] = mfma16(a[s][e], b[t][e], acc[t]);  // NT independent chains in a row
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = m0 + 4 * kk + r;
+        if (m >= p.M) continue;
+        float* crow = p.C + (size_t)m * p.N + i0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int i = 64 * g + 4 * j;
+            if (i0 + i >= p.N) continue;  // N % 4 == 0
+            f32x4 o = p.alpha * (f32x4){acc[4 * g][r], acc[4 * g + 1][r], acc[4 * g + 2][r], acc[4 * g + 3][r]};
+            if (p.beta != 0.f) o += p.beta * cpre[g][r];
+            *reinterpret_cast<f32x4*>(crow + i) = o;
+        }
+#pragma unroll
+        for (int t = 4 * G; t < NT; t++) {
+            const int i = irow[t];
+            if (i0 + i >= p.N) continue;
+            float o = p.alpha * acc[t][r];
+            if (p.beta != 0.f) o += p.beta * cpre1[t - 4 * G][r];
+            crow[i] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN, long K:  C[M x N] = alpha A[K x M]^T B[K x N] + beta C  (dX = W^T dY; K = thousands of classes).  Workgroup =
+// 4 waves owns an (MG*16 rows) x 64 columns tile of C for one K chunk; its waves take the chunk's k-steps (4 rows of A
+// and B each) round-robin in batches of U, all loads of a batch in flight before its MFMAs and the next batch
+// prefetched.  Row order: lane (j, kk) reads 4 consecutive m of row k0 + kk -> component u feeds tile u, whose row j is
+// m = 64h + 4j + u (h-th group of 64 rows); MG % 4 left-over tiles read one m per lane (m = base + 16u + j).
+// The waves' sums are combined through LDS in a fixed order; slab z of `part` gets the chunk's tile, and
+// k_fc_tn_reduce adds the slabs in index order.
+// ---------------------------------------------------------------------------------------------
+template <int MG, int U>
+__global__ __launch_bounds__(256) void k_fc_tn_split(const FcParams p) {
+    extern __shared__ f32x4 red[];
+    constexpr int H = MG / 4, R = MG % 4, T = MG * 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int mb = blockIdx.y * (16 * MG), nb = blockIdx.x * 64;
+    const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
+    f32x4 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = F4ZERO;
+    const bool nin = nb + 4 * j < p.N;  // N % 4 == 0
+    bool min4[H > 0 ? H : 1], min1[R > 0 ? R : 1];
+#pragma unroll
+    for (int h = 0; h < H; h++) min4[h] = mb + 64 * h + 4 * j < p.M;  // M % 4 == 0
+#pragma unroll
+    for (int u = 0; u < R; u++) min1[u] = mb + 64 * H + 16 * u + j < p.M;
+    const float* ab = p.A + mb;
+    const float* bb = p.B + nb + 4 * j;
+
+    f32x4 a40[U][H > 0 ? H : 1], a41[U][H > 0 ? H : 1], b0[U], b1[U];
+    float a10[U][R > 0 ? R : 1], a11[U][R > 0 ? R : 1];
+    auto load = [&](int kb, f32x4(&a4)[U][H > 0 ? H : 1], float(&a1)[U][R > 0 ? R : 1], f32x4(&b)[U]) {
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+            const int k = kb + 4 * s + kk;
+            const bool kin = k < kEnd;
+            const size_t kr = (size_t)min(k, p.K - 1);
+#pragma unroll
+            for (int h = 0; h < H; h++) a4[s][h] = (kin && min4[h]) ? ldg4(ab + kr * p.M + 64 * h + 4 * j) : F4ZERO;
+#pragma unroll
+            for (int u = 0; u < R; u++) a1[s][u] = (kin && min1[u]) ? ab[kr * p.M + 64 * H + 16 * u + j] : 0.f;
+            b[s] = (kin && nin) ? ldg4(bb + kr * p.N) : F4ZERO;
+        }
+    };
+    auto compute = [&](const f32x4(&a4)[U][H > 0 ? H : 1], const float(&a1)[U][R > 0 ? R : 1], const f32x4(&b)[U]) {
+#pragma unroll
+        for (int s = 0; s < U; s++) {
+#pragma unroll
+            for (int h = 0; h < H; h++)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) acc[(4 * h + u) * 4 + t] = mfma16(a4[s][h][u], b[s][t], acc[(4 * h + u) * 4 + t]);
+#pragma unroll
+            for (int u = 0; u < R; u++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) acc[(4 * H + u) * 4 + t] = mfma16(a1[s][u], b[s][t], acc[(4 * H + u) * 4 + t]);
+        }
+    };
+    constexpr int KB = 4 * U;
+    const int kStep = KB * 4;
+    const int kFirst = kBeg + wave * KB;
+    if (kFirst < kEnd) load(kFirst, a40, a10, b0);
+    for (int kb = kFirst; kb < kEnd; kb += 2 * kStep) {
+        const bool more1 = kb + kStep < kEnd, more2 = kb + 2 * kStep < kEnd;
+        if (more1) load(kb + kStep, a41, a11, b1);
+        compute(a40, a10, b0);
+        if (more1) {
+            if (more2) load(kb + 2 * kStep, a40, a10, b0);
+            compute(a41, a11, b1);
+        }
+    }
+
+    // fixed halving tree over the four waves, totals published so that every wave stores a share of the tile
+    for (int hh = 2; hh >= 1; hh >>= 1) {
+        __syncthreads();
+        if (wave >= hh && wave < 2 * hh) {
+#pragma unroll
+            for (int t = 0; t < T; t++) red[((wave - hh) * T + t) * 64 + lane] = acc[t];
+        }
+        __syncthreads();
+        if (wave < hh) {
+#pragma unroll
+            for (int t = 0; t < T; t++) acc[t] += red[(wave * T + t) * 64 + lane];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int t = 0; t < T; t++) red[t * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    float* slab = p.part + (size_t)blockIdx.z * p.M * p.N;
+    if (!nin) return;
+    // tile (mt, t): D row 4kk + r <-> lane-row index jA = 4kk + r of the A operand; column j <-> n = nb + 4j + t
+#pragma unroll
+    for (int mt = 0; mt < MG; mt++) {
+        if ((mt & 3) != wave) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int jA = 4 * kk + r;
+            const int m = mt < 4 * H ? mb + 64 * (mt / 4) + 4 * jA + (mt % 4) : mb + 64 * H + 16 * (mt - 4 * H) + jA;
+            if (m >= p.M) continue;
+            const f32x4 o = {red[(mt * 4 + 0) * 64 + lane][r], red[(mt * 4 + 1) * 64 + lane][r], red[(mt * 4 + 2) * 64 + lane][r],
+                             red[(mt * 4 + 3) * 64 + lane][r]};
+            *reinterpret_cast<f32x4*>(slab + (size_t)m * p.N + nb + 4 * j) = o;
+        }
+    }
+}
+
+// slabs [splits][M*N] -> C = alpha * sum + beta * C; one 16-byte column group per thread, slabs added in index order,
+// eight loads in flight
+__global__ __launch_bounds__(256) void k_fc_tn_reduce(const FcParams p) {
+    const size_t total4 = (size_t)p.M * p.N / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.part) + i;
+    f32x4 s = src[0];
+    int z = 1;
+    for (; z + 7 < p.splits; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t)(z + u) * total4];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; z < p.splits; z++) s += src[(size_t)z * total4];
+    f32x4* c = reinterpret_cast<f32x4*>(p.C) + i;
+    s = p.alpha * s;
+    if (p.beta != 0.f) s += p.beta * *c;
+    *c = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: which shapes take these forms (everything else stays with gemm.hip)
+// ---------------------------------------------------------------------------------------------
+static inline bool al16(const void* p) { return ((uintptr_t)p % 16) == 0; }
+
+bool fc_nn_lds_usable(const float* A, const float* B, const float* C, int M, int N, int K) {
+    return M >= 512 && N % 4 == 0 && K % 4 == 0 && K <= 4096 && al16(A) && al16(B) && al16(C);
+}
+bool fc_nt_lds_usable(const float* A, const float* B, const float* C, int M, int N, int K) {
+    return M >= 512 && N % 16 == 0 && N >= 64 && K % 4 == 0 && K <= 1024 && al16(A) && al16(B) && al16(C);
+}
+// TN with a long reduction and a small output
+struct TnPlan { int mg, splits, kChunk; };
+static TnPlan tn_plan(int M, int N, int K) {
+    TnPlan pl;
+    pl.mg = (M % 80 == 0 || M <= 80) && M > 64 ? 5 : 4;
+    const long tiles = (long)divup(M, 16 * pl.mg) * divup(N, 64);
+    long s = std::max<long>(1, 256 / tiles);
+    s = std::min<long>(s, std::max(1, K / 64));
+    pl.kChunk = divup(divup(K, (int)s), 16) * 16;
+    pl.splits = divup(K, pl.kChunk);
+    return pl;
+}
+bool fc_tn_split_usable(const float* A, const float* B, const float* C, int M, int N, int K) {
+    return K >= 2048 && (long)M * N <= 512 * 512 && M % 4 == 0 && N % 4 == 0 && al16(A) && al16(B) && al16(C);
+}
+size_t fc_tn_split_workspace_bytes(int M, int N, int K) { return (size_t)tn_plan(M, N, K).splits * M * N * sizeof(float); }
+
+static FcParams fc_params(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, float alpha, float beta,
+                          int neuron, float na, float nb) {
+    FcParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.smPart = nullptr; p.part = nullptr;
+    p.M = M; p.N = N; p.K = K; p.kChunk = K; p.splits = 1;
+    p.neuron = neuron; p.alpha = alpha; p.beta = beta; p.na = na; p.nb = nb;
+    return p;
+}
+
+int fc_nn_lds_launch(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, float alpha, float beta,
+                     int neuron, float na, float nb, float* smPart, hipStream_t s) {
+    FcParams p = fc_params(A, B, bias, C, M, N, K, alpha, beta, neuron, na, nb);
+    p.smPart = smPart;
+    dim3 grid(divup(M, 64), divup(N, 128));
+    MCN_REQUIRE(grid.y <= 65535, "gemm: grid too large");
+    // 160-row chunks when they waste nothing (K = 160), else 128
+    if (K % 160 == 0 || (K < 160 && K > 128)) hipLaunchKernelGGL((k_fc_nn_lds<10>), grid, dim3(256), 160 * 128 * 4, s, p);
+    else hipLaunchKernelGGL((k_fc_nn_lds<8>), grid, dim3(256), 128 * 128 * 4, s, p);
+    return MCN_LAUNCH_CHECK("gemm (fc nn)");
+}
+
+int fc_nt_lds_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, hipStream_t s) {
+    FcParams p = fc_params(A, B, nullptr, C, M, N, K, alpha, beta, MCN_NEURON_IDENT, 0.f, 0.f);
+    // column tile: 160 when it divides (fc6: 160 inputs), else 128 (DeepID2+: 512 inputs), else 64
+    const int nt = N % 160 == 0 ? 10 : (N % 128 == 0 || N > 128) ? 8 : 4;
+    dim3 grid(divup(M, 64), divup(N, 16 * nt));
+    MCN_REQUIRE(grid.y <= 65535, "gemm: grid too large");
+    const size_t lds = (size_t)16 * nt * 128 * 4;
+    if (nt == 10) hipLaunchKernelGGL((k_fc_nt_lds<10>), grid, dim3(256), lds, s, p);
+    else if (nt == 8) hipLaunchKernelGGL((k_fc_nt_lds<8>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((k_fc_nt_lds<4>), grid, dim3(256), lds, s, p);
+    return MCN_LAUNCH_CHECK("gemm (fc nt)");
+}
+
+int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, void* workspace,
+                       size_t workspaceBytes, hipStream_t s) {
+    const TnPlan pl = tn_plan(M, N, K);
+    const size_t need = (size_t)pl.splits * M * N * sizeof(float);
+    if (!workspace || workspaceBytes < need || !al16(workspace)) {
+        mcn_set_error("gemm: workspace %zu < %zu bytes", workspaceBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    FcParams p = fc_params(A, B, nullptr, C, M, N, K, alpha, beta, MCN_NEURON_IDENT, 0.f, 0.f);
+    p.part = (float*)workspace;
+    p.kChunk = pl.kChunk;
+    p.splits = pl.splits;
+    dim3 grid(divup(N, 64), divup(M, 16 * pl.mg), pl.splits);
+    MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+    if (pl.mg == 5) hipLaunchKernelGGL((k_fc_tn_split<5, 6>), grid, dim3(256), 2 * 20 * 64 * 16, s, p);
+    else hipLaunchKernelGGL((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
+    int rc = MCN_LAUNCH_CHECK("gemm (fc tn)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 256)), dim3(256), 0, s, p);
+    return MCN_LAUNCH_CHECK("gemm (fc tn reduce)");
+}

@@ -16,6 +16,7 @@
 // used only for very long K (fc6 backward-data).  Deterministic, no atomics.
 #include <algorithm>
 #include "common.h"
+#include "fc_gemm.h"
 
 struct GemmParams {
     const float* A;
@@ -402,7 +403,10 @@ static GemmPlan gemm_plan(int M, int N, int K, int ta, int tb) {
 MCN_API size_t mcn_gemm_workspace_bytes(int M, int N, int K, int transA, int transB) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const GemmPlan pl = gemm_plan(M, N, K, transA, transB);
-    return pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+    size_t b = pl.splits > 1 ? (size_t)pl.splits * M * N * sizeof(float) : 0;
+    // (either form may be chosen at launch, depending on the alignment of the pointers)
+    if (transA && !transB && fc_tn_split_usable(nullptr, nullptr, nullptr, M, N, K)) b = std::max(b, fc_tn_split_workspace_bytes(M, N, K));
+    return b;
 }
 
 static int gemm_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ta, int tb,
@@ -411,6 +415,16 @@ static int gemm_impl(const float* A, const float* B, const float* bias, float* C
     MCN_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, "gemm: bad argument");
     MCN_REQUIRE(!(ta && tb), "gemm: transA && transB is not used by any layer and is not supported");
     MCN_REQUIRE(neuron_valid(neuron), "gemm: bad neuron type");
+    // classifier-layer shapes: LDS-staged / row-split forms (fc_gemm.hip)
+    static const bool general = getenv("MCN_GEMM_GENERAL") != nullptr;  // (A/B switch: the general kernels for every shape)
+    if (!general) {
+        if (!ta && !tb && fc_nn_lds_usable(A, B, C, M, N, K))
+            return fc_nn_lds_launch(A, B, bias, C, M, N, K, alpha, beta, neuron, na, nb, nullptr, (hipStream_t)stream);
+        if (tb && !bias && neuron == MCN_NEURON_IDENT && fc_nt_lds_usable(A, B, C, M, N, K))
+            return fc_nt_lds_launch(A, B, C, M, N, K, alpha, beta, (hipStream_t)stream);
+        if (ta && !bias && neuron == MCN_NEURON_IDENT && fc_tn_split_usable(A, B, C, M, N, K))
+            return fc_tn_split_launch(A, B, C, M, N, K, alpha, beta, workspace, workspaceBytes, (hipStream_t)stream);
+    }
     const GemmPlan pl = gemm_plan(M, N, K, ta, tb);
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K;
@@ -473,6 +487,26 @@ MCN_API int mcn_gemm(const float* A, const float* B, float* C, int M, int N, int
                      float beta, void* workspace, size_t workspaceBytes, void* stream) {
     return gemm_impl(A, B, nullptr, C, M, N, K, transA, transB, alpha, beta, MCN_NEURON_IDENT, 0.f, 0.f, workspace,
                      workspaceBytes, stream);
+}
+
+// FCLayer::fpropActs under a softmax: the forward product that also leaves stage 1 of the softmax (per 64-row block and
+// case: max and sum of exp(x - max)) in softmaxPart, laid out like the workspace of mcn_softmax.
+MCN_API int mcn_gemm_softmax_part_supported(const float* A, const float* B, const float* C, int M, int N, int K) {
+    static const bool general = getenv("MCN_GEMM_GENERAL") != nullptr;
+    return (A && B && C && M > 0 && N > 0 && K > 0 && !general && fc_nn_lds_usable(A, B, C, M, N, K)) ? 1 : 0;
+}
+MCN_API int mcn_gemm_bias_neuron_softmax_part(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                                              int neuron, float neuronA, float neuronB, void* softmaxPart, size_t softmaxPartBytes,
+                                              void* stream) {
+    MCN_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && softmaxPart, "gemmSoftmaxPart: bad argument");
+    MCN_REQUIRE(neuron_valid(neuron), "gemmSoftmaxPart: bad neuron type");
+    MCN_REQUIRE(mcn_gemm_softmax_part_supported(A, B, C, M, N, K), "gemmSoftmaxPart: this shape has no fused form (M %d, N %d, K %d)", M, N, K);
+    const size_t need = mcn_softmax_workspace_bytes(M, N);
+    if (softmaxPartBytes < need) {
+        mcn_set_error("gemmSoftmaxPart: partial buffer %zu < %zu bytes", softmaxPartBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    return fc_nn_lds_launch(A, B, bias, C, M, N, K, 1.f, 0.f, neuron, neuronA, neuronB, (float*)softmaxPart, (hipStream_t)stream);
 }
 
 MCN_API int mcn_gemm_bias_neuron(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, float beta,

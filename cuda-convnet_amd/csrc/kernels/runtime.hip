@@ -112,6 +112,38 @@ MCN_API int mcn_event_elapsed_ms(float* ms, void* start, void* stop) {
 }
 
 // ---------------------------------------------------------------------------
+// Step graphs: everything issued on `stream` (and on streams that join it through events) between begin and end becomes
+// one executable graph; a replay costs one call instead of one per kernel / event / wait.
+// ---------------------------------------------------------------------------
+MCN_API int mcn_graph_begin_capture(void* stream) {
+    return mcn_check_hip(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+MCN_API int mcn_graph_end_capture(void* stream, void** graphExec, int* numNodes) {
+    MCN_REQUIRE(graphExec, "graphEndCapture: null pointer");
+    *graphExec = nullptr;
+    hipGraph_t g = nullptr;
+    int rc = mcn_check_hip(hipStreamEndCapture((hipStream_t)stream, &g), "hipStreamEndCapture");
+    if (rc) return rc;
+    if (numNodes) {
+        size_t n = 0;
+        (void)hipGraphGetNodes(g, nullptr, &n);
+        *numNodes = (int)n;
+    }
+    hipGraphExec_t e = nullptr;
+    rc = mcn_check_hip(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    (void)hipGraphDestroy(g);
+    if (rc) return rc;
+    *graphExec = (void*)e;
+    return MCN_OK;
+}
+MCN_API int mcn_graph_launch(void* graphExec, void* stream) {
+    return mcn_check_hip(hipGraphLaunch((hipGraphExec_t)graphExec, (hipStream_t)stream), "hipGraphLaunch");
+}
+MCN_API int mcn_graph_destroy(void* graphExec) {
+    return graphExec ? mcn_check_hip(hipGraphExecDestroy((hipGraphExec_t)graphExec), "hipGraphExecDestroy") : MCN_OK;
+}
+
+// ---------------------------------------------------------------------------
 // RCCL, loaded on first use so that single-GPU users never pay for it.
 // Only the entry points below are bound (signatures from rccl.h).
 // ---------------------------------------------------------------------------

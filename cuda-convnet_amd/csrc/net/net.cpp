@@ -210,17 +210,27 @@ void Layer::bprop(PassType pt) {  // layer.cu:116-121
     }
 }
 
+void Layer::awaitSeed() {
+    if (!_seeded) return;
+    _seeded = false;
+    _net->waitSideSubmitted(_seedTicket);  // the side thread has recorded the event
+    chk(timedStreamWait(_net->stream(), _seedEvent), "wait event");
+}
+
 void Layer::bpropWith(float* v, PassType pt) {  // layer.cu:123-158
+    awaitSeed();
     bpropCommon(v, pt);
     if (isGradProducer()) {
         for (int i = 0; i < (int)_prev.size(); i++) {
             if (_prev[i]->isGradConsumer() && _actsGradTarget != i) {
+                _prev[i]->awaitSeed();
                 ProfScope ps(_net, _name, "bpropActs", i);
                 bpropActs(v, i, _prev[i]->rcvdB() > 0 ? 1.f : 0.f, pt);
                 _prev[i]->incRcvdB();
             }
         }
         if (_actsGradTarget >= 0 && _prev[_actsGradTarget]->isGradConsumer()) {
+            _prev[_actsGradTarget]->awaitSeed();
             ProfScope ps(_net, _name, "bpropActs", _actsGradTarget);
             bpropActs(v, _actsGradTarget, _prev[_actsGradTarget]->rcvdB() > 0 ? 1.f : 0.f, pt);
             _prev[_actsGradTarget]->incRcvdB();
@@ -355,7 +365,15 @@ size_t FCLayer::workspaceBytes(int maxCases) {
 
 void FCLayer::fpropActs(int i, float scaleTargets, PassType) {
     const int n = _net->numCases(), I = _prev[i]->outputs();
-    if (scaleTargets == 0) {
+    if (scaleTargets == 0 && softmaxBelow && _net->fusion() && softmaxBelow->part.p &&
+        mcn_gemm_softmax_part_supported(_weights[i]->W(), _inputs[i], _acts, _outputs, n, I)) {
+        // classifier layer: the product also leaves stage 1 of the softmax that follows (no pass of its own over the acts)
+        chk(mcn_gemm_bias_neuron_softmax_part(_weights[i]->W(), _inputs[i], _biases->W(), _acts, _outputs, n, I,
+                                              fusedNeuron ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fusedNeuron ? fusedNeuron->spec.a : 0.f,
+                                              fusedNeuron ? fusedNeuron->spec.b : 0.f, softmaxBelow->part.p, softmaxBelow->partBytes,
+                                              _net->stream()), "fc fprop + softmax stage 1");
+        softmaxBelow->partReady = true;
+    } else if (scaleTargets == 0) {
         const bool fuse = fusedNeuron && _prev.size() == 1;
         chk(mcn_gemm_bias_neuron(_weights[i]->W(), _inputs[i], _biases->W(), _acts, _outputs, n, I, 0.f,
                                  fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fuse ? fusedNeuron->spec.a : 0.f,
@@ -483,20 +501,36 @@ void LocalLayer::bpropWeights(float* v, int i, PassType pt) {
 // ============================================================================ SoftmaxLayer (layer.cu:582-607)
 size_t SoftmaxLayer::workspaceBytes(int maxCases) { return mcn_softmax_workspace_bytes(_outputs, maxCases); }
 
+void SoftmaxLayer::allocate(int maxCases) {
+    Layer::allocate(maxCases);
+    partBytes = mcn_softmax_workspace_bytes(_outputs, maxCases);
+    part.ensure((partBytes + 3) / 4);
+}
+
 void SoftmaxLayer::fpropActs(int, float, PassType pt) {
     // a logreg cost on top (the DeepID nets): its gradient through this softmax needs only the probabilities and the
     // labels, so a training pass writes it while the probabilities are still in registers (one launch and one read of
     // the (classes, cases) matrix less on the backward chain).  Safe: fc's gradient buffer has no other writer.
     _gradFused = false;
+    const bool havePart = partReady;  // the producer's forward product of THIS pass left stage 1
+    partReady = false;
     CostLayer* cost = _next.size() == 1 && _next[0]->type() == "cost.logreg" ? static_cast<CostLayer*>(_next[0]) : nullptr;
     if (cost && pt != PASS_TEST && _net->fusion() && cost->coeff() != 0 && _prev[0]->isGradConsumer() && _prev[0]->next().size() == 1) {
         float* labels = cost->prev()[0]->getActs();
-        chk(mcn_softmax_logreg_grad(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(),
-                                    _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax + logreg grad");
+        if (havePart)
+            chk(mcn_softmax_from_part(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(), part.p,
+                                      partBytes, _net->stream()), "softmax stage 2 + logreg grad");
+        else
+            chk(mcn_softmax_logreg_grad(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(),
+                                        _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax + logreg grad");
         _gradFused = true;
         return;
     }
-    chk(mcn_softmax(_inputs[0], _acts, _outputs, _net->numCases(), _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax");
+    if (havePart)
+        chk(mcn_softmax_from_part(_inputs[0], _acts, nullptr, nullptr, 0.f, _outputs, _net->numCases(), part.p, partBytes, _net->stream()),
+            "softmax stage 2");
+    else
+        chk(mcn_softmax(_inputs[0], _acts, _outputs, _net->numCases(), _net->workspace(), _net->workspaceBytes(), _net->stream()), "softmax");
 }
 
 void SoftmaxLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
@@ -708,7 +742,7 @@ void L2SNCostLayer::allocate(int maxCases) {
 
 // The pair statistics, the margin search and the cost run on the side stream as soon as the features exist, next to
 // the rest of the forward pass; the backward pass waits for them and is then one elementwise launch.
-void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
+void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-1071
     if (i != 0) return;
     const int n = _net->numCases(), D = _prev[1]->outputs(), h = n / 2;
     // data parallel: the data-dependent margin must be the one a single GPU would pick on the global minibatch
@@ -729,7 +763,16 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         });
         return;
     }
-    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather] {
+    // Training pass on one GPU: the gradient (one elementwise launch from the kept statistics) follows the cost on the side
+    // stream right away and is the FIRST gradient its input receives this pass; the backward chain then accumulates onto it
+    // (a + b == b + a: same bits as the reference order, layer.cu:1073-1082 after fc6's) instead of stopping for it.
+    float* early = nullptr;
+    static const bool noEarly = getenv("MCN_NO_EARLY_L2SN") != nullptr;  // (A/B switch)
+    if (!noEarly && !gather && !_net->dataParallel() && pt == PASS_TRAIN && _coeff != 0 && _net->fusion() && _prev[1]->isGradConsumer() &&
+        _prev[1]->rcvdB() == 0)
+        early = _prev[1]->getActsGrad();
+    const float coeff = _coeff;
+    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather, early, coeff] {
         if (gather) {
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
             _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
@@ -737,8 +780,20 @@ void L2SNCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1060-1071
         }
         chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, gather ? nullptr : _pairStats.p, dCost, gather ? _gathered.p : nullptr,
                           gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+        if (early) chk(mcn_l2sn_grad_from_stats(data, early, D, n, _pairStats.p, _info.p, 0, coeff, _net->stream()), "l2sn grad (early)");
         chk(timedEventRecord(_evReady, _net->stream()), "event record");
     });
+    _earlyGrad = early != nullptr;
+    if (early) _prev[1]->seedGrad(_evReady, _readyTicket);
+}
+
+void L2SNCostLayer::bprop(PassType pt) {
+    if (!_earlyGrad) {
+        CostLayer::bprop(pt);
+        return;
+    }
+    _earlyGrad = false;  // delivered during forward; pass the turn on as Layer::bpropWith would (layer.cu:150-156)
+    if (_prev[1]->isGradConsumer()) _prev[1]->bprop(pt);
 }
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
@@ -820,6 +875,15 @@ void DataProvider::setData(const CPUData& d) {
     }
 }
 
+bool DataProvider::sliceIsPointer(long start, long end) const {
+    end = std::min(end, _numCases);
+    if (!_onDevice || end <= start) return false;
+    if (end - start == _numCases) return true;
+    for (size_t i = 0; i < _dims.size(); i++)
+        if (!(start % _minibatchSize == 0 && end == std::min(start + _minibatchSize, _numCases) && ((size_t)start * _dims[i]) % 4 == 0)) return false;
+    return true;
+}
+
 void DataProvider::getSlice(long start, long end, std::vector<float*>& out) {
     end = std::min(end, _numCases);
     const long n = end - start;
@@ -890,8 +954,14 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
     _dp.reset(new DataProvider(this, minibatchSize));
 }
 
+void ConvNet::dropStepGraphs() {
+    for (auto& kv : _stepGraphs) mcn_graph_destroy(kv.second.exec);
+    _stepGraphs.clear();
+}
+
 ConvNet::~ConvNet() {
     stop();
+    dropStepGraphs();
     _side.stop();
     _commSub.stop();
     if (getenv("MCN_DEBUG_TIMES") && _rcclCalls) fprintf(stderr, "[mcn] all-reduce calls: %ld, host us per call: %.1f\n", (long)_rcclCalls, _rcclCallNs / 1e3 / _rcclCalls);
@@ -923,6 +993,15 @@ void ConvNet::buildFusions() {
                     w->fusedNeuron = r;
                     r->fwdFused = true;
                 }
+            }
+        }
+        // classifier layer directly under a softmax: stage 1 of the softmax in the epilogue of the forward product
+        // (possibly through the neuron layer fused into that product above: `neuron=ident` in the DeepID cfgs)
+        if (auto* fc = dynamic_cast<FCLayer*>(up.get())) {
+            if (fc->prev().size() == 1 && fc->next().size() == 1) {
+                Layer* below = fc->fusedNeuron ? (fc->fusedNeuron->next().size() == 1 ? fc->fusedNeuron->next()[0] : nullptr) : fc->next()[0];
+                if (auto* sm = dynamic_cast<SoftmaxLayer*>(below))
+                    if (sm->prev().size() == 1) fc->softmaxBelow = sm;
             }
         }
         // backward: max pool directly above a neuron layer that (a) gets gradient from nobody else,
@@ -977,6 +1056,9 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
     chk(mcn_set_device(_deviceID < 0 ? 0 : _deviceID), "set device");
     chk(mcn_stream_create(&_stream), "stream");
     if (const char* e = getenv("MCN_SIDE_UNITS")) _sideUnits = std::max(1, atoi(e));
+    // opt-in: on this runtime (ROCm 7.2) a replayed step takes longer on the device than the eagerly submitted one
+    // (0.400 vs 0.356 ms, DeepID2) although it needs half the host time -- DESIGN.md section 5
+    _useGraphs = getenv("MCN_STEP_GRAPH") != nullptr;
     if (getenv("MCN_NO_GRAD_STREAM") == nullptr) {
         chk(mcn_stream_create(&_gradStream), "grad stream");
         chk(mcn_event_create_sync(&_evJoin), "event");
@@ -1053,6 +1135,7 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     _rank = rank;
     _world = world;
     _dpOn = world > 1 || force;
+    dropStepGraphs();
     if (_dpOn) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
         chk(mcn_stream_create(&_commStream), "comm stream");
@@ -1167,7 +1250,7 @@ long ConvNet::forkSideWork(std::function<void()> fn) {
     }
     _deferred.emplace_back(std::move(fn), 0);
     flushSideWork(_deferred.size());  // (together with what was deferred before: keeps the order)
-    return _side.pushed();
+    return _capturing ? 0 : _side.pushed();
 }
 
 // the first `count` deferred items become one task of the side thread, ordered after everything the main stream
@@ -1185,6 +1268,20 @@ void ConvNet::flushSideWork(size_t count) {
     }
     _deferred.erase(_deferred.begin(), _deferred.begin() + count);
     _gradPending = true;
+    if (_capturing) {
+        // graph capture: this thread issues the side stream's work itself -- the fork event pulls the side stream into the
+        // capture, and the recorded graph carries the dependency instead of a host thread
+        chk(mcn_stream_wait_event(_gradStream, forkEvent), "wait event");
+        t_stream = 1;
+        try {
+            for (auto& fn : *fns) fn();
+        } catch (...) {
+            t_stream = 0;
+            throw;
+        }
+        t_stream = 0;
+        return;
+    }
     _side.push([this, forkEvent, fns] {
         t_stream = 1;
         chk(timedStreamWait(_gradStream, forkEvent), "wait event");
@@ -1267,7 +1364,7 @@ void ConvNet::joinGradWork() {
     runLateWork();
     joinExchange();
     if (!_gradPending) return;
-    _side.wait(_side.pushed());  // the side thread has issued everything it was given
+    if (!_capturing) _side.wait(_side.pushed());  // the side thread has issued everything it was given
     chk(timedEventRecord(_evJoin, _gradStream), "event record");
     chk(timedStreamWait(_stream, _evJoin), "wait event");
     _gradPending = false;
@@ -1320,6 +1417,57 @@ void ConvNet::updateWeights() {  // convnet.cu:190-194
     } else {
         for (auto& l : _layers) l->updateWeights();
     }
+}
+
+// ---- step graphs -------------------------------------------------------------------------------
+bool ConvNet::stepGraphUsable(int miniIdx) {
+    if (!_useGraphs || _dpOn || _profiling || _phases || !_fusion || _stepsDone == 0) return false;  // (the first step runs eagerly: it learns the pass structure)
+    const long start = (long)miniIdx * _minibatchSize, end = std::min(start + _minibatchSize, _dp->numCases());
+    return _dp->sliceIsPointer(start, end);
+}
+
+void ConvNet::captureStep(int miniIdx, StepGraph& g) {
+    joinGradWork();  // nothing may be pending on the side stream when the capture starts
+    chk(mcn_graph_begin_capture(_stream), "begin capture");
+    _capturing = true;
+    try {
+        fprop(miniIdx, PASS_TRAIN);
+        bprop(PASS_TRAIN);
+        updateWeights();
+        joinGradWork();
+    } catch (...) {
+        _capturing = false;
+        void* dead = nullptr;
+        mcn_graph_end_capture(_stream, &dead, nullptr);
+        mcn_graph_destroy(dead);
+        throw;
+    }
+    _capturing = false;
+    chk(mcn_graph_end_capture(_stream, &g.exec, &g.nodes), "end capture");
+    g.data = _curData;
+    g.numCases = _numCases;
+}
+
+void ConvNet::trainStep(int miniIdx) {
+    if (stepGraphUsable(miniIdx)) {
+        const long start = (long)miniIdx * _minibatchSize, end = std::min(start + _minibatchSize, _dp->numCases());
+        std::vector<float*> slice;
+        _dp->getSlice(start, end, slice);  // pointers only
+        StepGraph& g = _stepGraphs[miniIdx];
+        if (g.exec && (g.data != slice || g.numCases != (int)(end - start))) {  // the batch moved or changed shape
+            mcn_graph_destroy(g.exec);
+            g = StepGraph();
+        }
+        if (!g.exec) captureStep(miniIdx, g);  // (capturing runs nothing)
+        _numCases = g.numCases;
+        _curData = g.data;
+        chk(mcn_graph_launch(g.exec, _stream), "graph launch");
+    } else {
+        fprop(miniIdx, PASS_TRAIN);
+        bprop(PASS_TRAIN);
+        updateWeights();
+    }
+    _stepsDone++;
 }
 
 void ConvNet::copyToCPU() {

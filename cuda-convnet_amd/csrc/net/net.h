@@ -109,7 +109,12 @@ class Layer {
     // layer.cu:116-158
     virtual void bprop(PassType pt);
     void bpropWith(float* v, PassType pt);
-    void reset() { _rcvdF = _rcvdB = 0; }
+    void reset() { _rcvdF = _rcvdB = 0; _seeded = false; }
+    // A cost layer may deliver its gradient into this layer's gradient matrix ahead of the backward pass, on the side
+    // stream (L2-SN: as soon as its cost statistics exist).  That counts as the first received gradient (everyone after it
+    // accumulates), and whoever touches the matrix first during backward waits for the event.
+    void seedGrad(void* event, long sideTicket) { _seeded = true; _seedEvent = event; _seedTicket = sideTicket; _rcvdB++; }
+    void awaitSeed();
     void addPrev(Layer* l) { _prev.push_back(l); }
     void addNext(Layer* l) { _next.push_back(l); _numGradProducersNext += l->isGradProducer(); }
     bool isGradConsumer();
@@ -152,6 +157,9 @@ class Layer {
     bool _gradConsumer, _foundGradConsumers = false;
     int _numGradProducersNext = 0, _rcvdF = 0, _rcvdB = 0;
     DBuf _ownActs, _ownActsGrad;
+    bool _seeded = false;
+    void* _seedEvent = nullptr;
+    long _seedTicket = 0;
     float* _acts = nullptr;  // current activity matrix (own buffer, shared input, or data slice)
 };
 
@@ -196,10 +204,12 @@ class WeightLayer : public Layer {
     float _wStep = 0.001f, _bStep = 0.002f;  // layer.cu:294-295
 };
 
+class SoftmaxLayer;
 class FCLayer : public WeightLayer {
    public:
     FCLayer(ConvNet* net, const Params& p);
     size_t workspaceBytes(int maxCases) override;
+    SoftmaxLayer* softmaxBelow = nullptr;  // the only consumer is a softmax: the forward product leaves its stage-1 partials
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
@@ -225,6 +235,10 @@ class SoftmaxLayer : public Layer {
    public:
     using Layer::Layer;
     size_t workspaceBytes(int maxCases) override;
+    void allocate(int maxCases) override;
+    DBuf part;               // stage-1 partials written by the producing FC layer's forward product
+    size_t partBytes = 0;
+    bool partReady = false;  // ... for the pass in flight
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
@@ -331,6 +345,7 @@ class L2SNCostLayer : public CostLayer {
    public:
     L2SNCostLayer(ConvNet* net, const Params& p);
     ~L2SNCostLayer() override;
+    void bprop(PassType pt) override;
     size_t actsElems(int n) const override { return (size_t)n; }
     void allocate(int maxCases) override;
    protected:
@@ -343,6 +358,7 @@ class L2SNCostLayer : public CostLayer {
     long _readyTicket = 0;
     bool _readyOnExchange = false;
     int _extCount = 0;
+    bool _earlyGrad = false;  // this pass already sent its gradient (forward, side stream)
 };
 
 class Fisher2CostLayer : public CostLayer {  // layer.cu:1017-1047
@@ -382,6 +398,7 @@ class DataProvider {
     int minibatchSize() const { return _minibatchSize; }
     long numCases() const { return _numCases; }
     bool resident() const { return _onDevice; }
+    bool sliceIsPointer(long start, long end) const;  // getSlice would hand out pointers into the tiled batch (no copy, no sync)
    private:
     ConvNet* _net;
     int _minibatchSize;
@@ -510,6 +527,11 @@ class ConvNet {
     // no allocation, one cost read-back at the end).  profile: bracket every layer operation with events.
     // profile 2: only the phases of a step (forward / backward-data chain / gradient tail / update), streams as in a normal run.
     void runSteps(int numSteps, bool test, int profile);
+    // One training minibatch (fprop + bprop + update).  When the minibatch is a pointer into a resident, tiled batch the
+    // whole step -- both streams, every fork and join -- is captured once per minibatch index into an executable graph and
+    // replayed afterwards: one submission per step instead of ~45 launches, ~10 event operations and two thread hand-overs.
+    void trainStep(int miniIdx);
+    void dropStepGraphs();
 
     // ---- services for layers ---------------------------------------------------------------
     void* stream() const;                       // the stream layer operations are issued on right now (per submitting thread)
@@ -614,6 +636,14 @@ class ConvNet {
     size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
     size_t _bucketFloats = 1 << 20;
     bool _commPending = false;
+
+    // step graphs
+    struct StepGraph { void* exec = nullptr; std::vector<float*> data; int numCases = 0; int nodes = 0; };
+    std::map<int, StepGraph> _stepGraphs;  // by minibatch index
+    bool _useGraphs = true, _capturing = false;
+    long _stepsDone = 0;
+    bool stepGraphUsable(int miniIdx);
+    void captureStep(int miniIdx, StepGraph& g);
 
     // per-operation event timing (off on the normal path)
     bool _profiling = false, _phases = false;

@@ -77,11 +77,8 @@ void ConvNet::runTraining(const CPUData& data, bool test, bool useResident) {
     WorkResult res;
     zeroCosts();
     for (int i = 0; i < _dp->numMinibatches(); i++) {
-        fprop(i, test ? PASS_TEST : PASS_TRAIN);
-        if (!test) {
-            bprop(PASS_TRAIN);
-            updateWeights();
-        }
+        if (test) fprop(i, PASS_TEST);
+        else trainStep(i);
     }
     readCosts(res.cost, _dp->numCases());
     _dp->clearHost();
@@ -102,6 +99,11 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
     g_eventCallMs = 0;
     try {
         for (int s = 0; s < numSteps; s++) {
+            if (!test && !profile) {
+                trainStep(s % nm);
+                cases += _numCases;
+                continue;
+            }
             if (_phases) profBegin("phase.forward");
             fprop(s % nm, test ? PASS_TEST : PASS_TRAIN);
             if (_phases) profEnd();
@@ -111,6 +113,7 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
                 if (_phases) profBegin("phase.update");
                 updateWeights();
                 if (_phases) profEnd();
+                _stepsDone++;
             }
         }
         const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -80,6 +80,14 @@ int mcn_event_sync(void* event);
 int mcn_stream_wait_event(void* stream, void* event);
 int mcn_event_elapsed_ms(float* ms, void* start, void* stop);
 
+/* Step graphs (no counterpart in the reference, whose step is ~45 launches and several blocking copies per minibatch):
+ * everything issued on `stream`, and on streams that join it through events, between begin and end is captured into one
+ * executable graph (nothing runs during capture); mcn_graph_launch replays it on a stream.  numNodes may be NULL. */
+int mcn_graph_begin_capture(void* stream);
+int mcn_graph_end_capture(void* stream, void** graphExec, int* numNodes);
+int mcn_graph_launch(void* graphExec, void* stream);
+int mcn_graph_destroy(void* graphExec);
+
 /* ---- cudaconv2.cuh:36-78 ------------------------------------------------------------------ */
 /* convFilterActs (cudaconv2.cuh:39-42, filter_acts.cu:1188-1193) / localFilterActs (:47-50, :1201-1206).
  * images (numImgColors*imgSizeY*imgSizeX, numImages) with row stride imgStride (>= numImages);
@@ -218,6 +226,14 @@ int mcn_gemm(const float* A, const float* B, float* C, int M, int N, int K, int 
 int mcn_gemm_bias_neuron(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
                          float beta, int neuron, float neuronA, float neuronB,
                          void* workspace, size_t workspaceBytes, void* stream);
+/* The same forward product for the layer directly under a softmax (FCLayer::fpropActs layer.cu:355-360 followed by
+ * SoftmaxLayer::fpropActs layer.cu:585-595): additionally leaves stage 1 of the softmax -- per 64-row block and case,
+ * max and sum of exp(x - max) -- in softmaxPart (mcn_softmax_workspace_bytes(M, N) bytes), for mcn_softmax_from_part.
+ * Only shapes for which mcn_gemm_softmax_part_supported returns 1 (tall A, 16-byte aligned, N and K multiples of 4). */
+int mcn_gemm_softmax_part_supported(const float* A, const float* B, const float* C, int M, int N, int K);
+int mcn_gemm_bias_neuron_softmax_part(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                                      int neuron, float neuronA, float neuronB, void* softmaxPart, size_t softmaxPartBytes,
+                                      void* stream);
 /* addVector (nvmatrix.cu:652-690): mat(rows x cols) += scale*vec; perRow=1: vec[rows], 0: vec[cols]. */
 int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream);
 /* addSum (nvmatrix.cu:896-906 -> _aggregate :700-805): tgt = scaleThis*tgt + scaleSum*sum(mat, axis).
@@ -243,6 +259,10 @@ int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream
 size_t mcn_softmax_workspace_bytes(int numOut, int numCases);
 int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes,
                 void* stream);
+/* Stage 2 of mcn_softmax / mcn_softmax_logreg_grad alone, from the partials mcn_gemm_bias_neuron_softmax_part left
+ * (labels and gradTarget both NULL: probabilities only). */
+int mcn_softmax_from_part(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
+                          int numCases, const void* part, size_t partBytes, void* stream);
 /* Softmax plus, in the same pass, what computeLogregSoftmaxGrad (layer_kernels.cu:287-308) would write for a logreg
  * cost on top of it: gradTarget[k,n] = coeff*((labels[n] == k) - probs[k,n]) (overwrite; bit-identical to the separate call). */
 int mcn_softmax_logreg_grad(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,

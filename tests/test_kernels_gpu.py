@@ -396,11 +396,12 @@ def test_relu_in_place():
 
 
 # ----------------------------------------------------------------------------------- GEMM (FC layers)
-FC_SHAPES = [(160, 1024), (160, 1200), (4213, 160), (10575, 160), (512, 2048), (10, 1024), (27, 160), (2, 160)]
+FC_SHAPES = [(160, 1024), (160, 1200), (4213, 160), (10575, 160), (512, 2048), (10, 1024), (27, 160), (2, 160), (10575, 512), (4131, 176),
+             (1000, 96)]
 
 
 @pytest.mark.parametrize('O_,I', FC_SHAPES)
-@pytest.mark.parametrize('N', [128, 33])
+@pytest.mark.parametrize('N', [128, 33, 72, 256])
 def test_fc_gemms(O_, I, N):
     rng = np.random.default_rng(18)
     W = mk(rng, O_, I, scale=0.01)      # Fortran-order (I, O) host matrix == [O][I] in memory (layer.py:788)
@@ -437,6 +438,39 @@ def test_fc_gemms(O_, I, N):
     inc0 = mk(rng, O_, I, scale=0.01)
     want = O.gemm(dY, X, O_, I, N, tb=True, alpha=5e-4 / N, beta=0.9, Cmat=inc0.copy())
     close(run(dY, X, inc0, O_, I, N, 0, 1, 5e-4 / N, 0.9), want, what='bwd-weights')
+
+
+@pytest.mark.parametrize('O_,I,N', [(10575, 160, 128), (4213, 160, 72), (10575, 512, 128), (1000, 96, 256), (4131, 160, 4)])
+def test_fc_forward_with_softmax_partials(O_, I, N):
+    """The classifier layer's forward product leaving stage 1 of the softmax (per 64-row block: max, sum exp(x - max)),
+    then stage 2 alone: x and probabilities against the oracle, the logreg gradient against the oracle's, argmax exact."""
+    rng = np.random.default_rng(180)
+    W = mk(rng, O_, I, scale=0.05)
+    X = mk(rng, I, N)
+    b = mk(rng, O_, scale=0.1)
+    labels = rng.integers(0, O_, (1, N)).astype(np.float32)
+    want_x = O.gemm(W, X, O_, N, I)
+    O.add_vector(want_x, b, O_, N, True)
+    want_p = O.softmax(want_x, O_, N)
+    d_W, d_X, d_x = dev(W), dev(X), dev_empty((O_, N), np.nan)
+    assert capi.lib().raw('mcn_gemm_softmax_part_supported')(d_W.ptr, d_X.ptr, d_x.ptr, O_, N, I) == 1
+    nb = ws_bytes('mcn_softmax_workspace_bytes', O_, N)
+    part = capi.workspace(nb)
+    call('mcn_gemm_bias_neuron_softmax_part', d_W, d_X, dev(b), d_x, O_, N, I, 0, 0.0, 0.0, part, nb, None)
+    close(d_x.numpy(), want_x, what='fc forward')
+    d_p, d_g = dev_empty((O_, N), np.nan), dev_empty((O_, N), np.nan)
+    call('mcn_softmax_from_part', d_x, d_p, dev(labels), d_g, 0.5, O_, N, part, nb, None)
+    got_p = d_p.numpy()
+    close(got_p, want_p, what='softmax from partials')
+    assert np.array_equal(np.argmax(got_p, axis=0), np.argmax(want_p, axis=0))
+    assert np.allclose(got_p.sum(axis=0), 1.0, atol=1e-5)
+    want_g = O.logreg_softmax_grad(labels, want_p, O_, N, 0.5)
+    close(d_g.numpy(), want_g, what='logreg gradient')
+    # the same partials as the stand-alone stage 1 would leave them, up to rounding of the sums
+    d_p2 = dev_empty((O_, N), np.nan)
+    part2 = capi.workspace(nb)
+    call('mcn_softmax', d_x, d_p2, O_, N, part2, nb, None)
+    close(d_p2.numpy(), got_p, rtol=1e-5, what='fused vs stand-alone softmax')
 
 
 def test_gemm_odd_sizes():

@@ -112,3 +112,47 @@ def test_two_streams_equal_one_stream_bitwise(name):
                 assert np.array_equal(a, b), '%s %s[%d] differs between the two-stream and the one-stream schedule' % (la['name'], key, i)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), '%s %s differs between the two-stream and the one-stream schedule' % (la['name'], key)
+
+
+def run_resident_steps(name, env, steps=8):
+    dp, L = preset(name, 384)  # three minibatches: every step graph is captured once and replayed at least once
+    data = dp.get_next_batch()[2]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with Native(L) as lib:
+            lib.loadBatch(data)
+            lib.startSteps(steps, 0, 0)
+            costs = lib.finishBatch()
+            lib.startBatch([], 0)       # the same graphs through the training worker (three more steps)
+            costs2 = lib.finishBatch()
+            lib.syncWithHost()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return L, costs, costs2
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_step_graph_replay_equals_eager_bitwise(name):
+    """A step captured into an executable graph (both streams, every fork and join as graph edges) and replayed must
+    leave exactly the weights the eagerly submitted step leaves: a dependency the capture misses -- one that eager
+    execution satisfies only by timing -- shows up here (round 1 saw a wrong L2-SN cost under capture)."""
+    La, ca, ca2 = run_resident_steps(name, {'MCN_STEP_GRAPH': '1'})
+    Lb, cb, cb2 = run_resident_steps(name, {})
+    for got, want in ((ca, cb), (ca2, cb2)):
+        assert got[1] == want[1]
+        for k in want[0]:
+            for a, b in zip(got[0][k], want[0][k]):
+                assert abs(a - b) <= 1e-9 * abs(b), (k, got[0][k], want[0][k])  # (double atomics: order of the adds)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between graph replay and eager submission' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between graph replay and eager submission' % (la['name'], key)
