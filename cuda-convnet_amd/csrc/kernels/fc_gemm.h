@@ -12,3 +12,11 @@ int fc_nn_lds_launch(const float* A, const float* B, const float* bias, float* C
 int fc_nt_lds_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, hipStream_t s);
 int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, void* workspace,
                        size_t workspaceBytes, hipStream_t s);
+
+// all inputs of a hidden FC layer in one launch (forward / backward-data)
+bool fc_fprop_multi_usable(const float* const* W, const float* const* X, const int* K, int count, const float* Y, int M, int N);
+int fc_fprop_multi_launch(const float* const* W, const float* const* X, const int* K, int count, const float* bias, float* Y, int M,
+                          int N, float beta, int neuron, float na, float nb, hipStream_t s);
+bool fc_bprop_multi_usable(const float* const* W, float* const* dX, const int* Mi, int count, const float* dY, int K, int N);
+int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi, const float* beta, const float* const* nacts,
+                          const int* ntype, const float* na, const float* nb, int count, const float* dY, int K, int N, hipStream_t s);

@@ -494,3 +494,266 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     hipLaunchKernelGGL(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 256)), dim3(256), 0, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc tn reduce)");
 }
+
+// =============================================================================================
+// A hidden FC layer with several inputs (DeepID's fc5 reads local4 AND pool3, layer.cu:355-366 loops over the inputs
+// with one cublasSgemm each): small outputs (160 x 128 cases), long reductions, launches that are pure latency.
+// One launch per direction for all inputs.
+// =============================================================================================
+#define FCM_MAXSEG 4
+struct FcMultiParams {
+    const float* A[FCM_MAXSEG];   // forward: W_i [M x K_i];  backward: W_i [K x M_i] (the same memory, read the other way)
+    const float* B[FCM_MAXSEG];   // forward: X_i [K_i x N]
+    float* C[FCM_MAXSEG];         // backward: dX_i [M_i x N]
+    const float* nacts[FCM_MAXSEG];  // backward: output of the neuron that produced X_i (gradient applied in the epilogue), or null
+    int K[FCM_MAXSEG];            // forward: K_i;  backward: M_i
+    int steps[FCM_MAXSEG];        // forward: K_i / 16;  backward: 32-row tiles of segment i
+    float beta[FCM_MAXSEG];
+    int ntype[FCM_MAXSEG];
+    float na[FCM_MAXSEG], nb[FCM_MAXSEG];
+    int nseg, totalSteps;
+    const float* bias;
+    const float* dY;              // backward: [K x N]
+    float* Y;                     // forward: [M x N]
+    int M, N, Kb;                 // forward: M, N;  backward: Kb = K (outputs of the layer), N
+    int neuron;
+    float fa, fb, fbeta;
+};
+
+// ---- forward: Y[M x N] = sum_i W_i X_i (+ bias, neuron).  One workgroup of 8 waves per 16 x 16 tile of Y; the waves split the
+// concatenated reduction (every K_i a multiple of 16) into 8 contiguous ranges and request their fragments in batches of U
+// 16-deep steps (next batch in flight while the current one multiplies); fixed-order tree over the waves through LDS.
+template <int U>
+__global__ __launch_bounds__(512) void k_fc_fprop_multi(const FcMultiParams p) {
+    __shared__ f32x4 red[4 * 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    const int per = (p.totalSteps + 7) / 8;
+    const int sBeg = wave * per, sEnd = min(p.totalSteps, sBeg + per);
+    const int mrow = min(m0 + j, p.M - 1);
+    const bool nin = n0 + j < p.N;
+    const int ncol = min(n0 + j, p.N - 1);
+    f32x4 acc = F4ZERO;
+    f32x4 a0[U], a1[U];
+    float b0[U][4], b1[U][4];
+    auto load = [&](int s0, f32x4(&a)[U], float(&b)[U][4]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int s = s0 + u;
+            if (s < sEnd) {  // wave-uniform
+                int seg = 0, ks = s;
+                while (ks >= p.steps[seg]) { ks -= p.steps[seg]; seg++; }
+                const float* ap = p.A[seg] + (size_t)mrow * p.K[seg] + 16 * ks + 4 * kk;
+                a[u] = ldg4(ap);
+                const float* bp = p.B[seg] + (size_t)(16 * ks + 4 * kk) * p.N + ncol;
+#pragma unroll
+                for (int e = 0; e < 4; e++) b[u][e] = nin ? bp[(size_t)e * p.N] : 0.f;
+            } else {
+                a[u] = F4ZERO;
+#pragma unroll
+                for (int e = 0; e < 4; e++) b[u][e] = 0.f;
+            }
+        }
+    };
+    auto compute = [&](const f32x4(&a)[U], const float(&b)[U][4]) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc = mfma16(a[u][e], b[u][e], acc);
+    };
+    if (sBeg < sEnd) load(sBeg, a0, b0);
+    for (int s = sBeg; s < sEnd; s += 2 * U) {
+        const bool more1 = s + U < sEnd, more2 = s + 2 * U < sEnd;
+        if (more1) load(s + U, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(s + 2 * U, a0, b0);
+            compute(a1, b1);
+        }
+    }
+    // fixed halving tree over the 8 waves
+    for (int hh = 4; hh >= 1; hh >>= 1) {
+        __syncthreads();
+        if (wave >= hh && wave < 2 * hh) red[(wave - hh) * 64 + lane] = acc;
+        __syncthreads();
+        if (wave < hh) acc += red[wave * 64 + lane];
+    }
+    if (wave != 0 || !nin) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = m0 + 4 * kk + r;
+        if (m >= p.M) continue;
+        float* c = p.Y + (size_t)m * p.N + n0 + j;
+        float o = acc[r];
+        if (p.fbeta != 0.f) o += p.fbeta * *c;
+        if (p.bias) o += p.bias[m];
+        if (p.neuron != MCN_NEURON_IDENT) o = neuron_apply(p.neuron, o, p.fa, p.fb);
+        *c = o;
+    }
+}
+
+// ---- backward-data: dX_i[M_i x N] = beta_i dX_i + W_i^T dY  (K = outputs of the layer, short: 160).  One WAVE per
+// 32 x 32 tile of one dX_i: lane (j, kk) reads 2 consecutive m of W row k0 + kk and 2 consecutive n of dY row k0 + kk
+// (component u / t feeds tile (u, t): rows m0 + 2j + u, columns n0 + 2j + t), ALL k-steps requested up front in batches of
+// U, no LDS, no barrier.  Optional epilogue: the gradient of the neuron that produced X_i, from its output.
+template <int U>
+__global__ __launch_bounds__(64) void k_fc_bprop_multi(const FcMultiParams p) {
+    const int lane = threadIdx.x, kk = lane >> 4, j = lane & 15;
+    int seg = 0, tile = blockIdx.y;
+    while (tile >= p.steps[seg]) { tile -= p.steps[seg]; seg++; }
+    const int M = p.K[seg], m0 = tile * 32, n0 = blockIdx.x * 32;
+    const float* A = p.A[seg];
+    const bool min2 = m0 + 2 * j < M, nin2 = n0 + 2 * j < p.N;  // M, N even
+    const float* ab = A + min(m0 + 2 * j, M - 2);
+    const float* bb = p.dY + min(n0 + 2 * j, p.N - 2);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = F4ZERO;
+    // epilogue operands first
+    const float beta = p.beta[seg];
+    f32x2 cold[2][4], nact[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + 2 * (4 * kk + r) + u;
+            const size_t off = (size_t)min(m, M - 1) * p.N + min(n0 + 2 * j, p.N - 2);
+            cold[u][r] = beta != 0.f ? *reinterpret_cast<const f32x2*>(p.C[seg] + off) : (f32x2){0.f, 0.f};
+            nact[u][r] = p.nacts[seg] ? *reinterpret_cast<const f32x2*>(p.nacts[seg] + off) : (f32x2){1.f, 1.f};
+        }
+    const int ksteps = (p.Kb + 3) / 4;
+    f32x2 a0[U], a1[U], b0[U], b1[U];
+    auto load = [&](int s0, f32x2(&a)[U], f32x2(&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = 4 * (s0 + u) + kk;
+            const bool kin = k < p.Kb;
+            const size_t kr = (size_t)min(k, p.Kb - 1);
+            a[u] = (kin && min2) ? *reinterpret_cast<const f32x2*>(ab + kr * M) : (f32x2){0.f, 0.f};
+            b[u] = (kin && nin2) ? *reinterpret_cast<const f32x2*>(bb + kr * p.N) : (f32x2){0.f, 0.f};
+        }
+    };
+    auto compute = [&](const f32x2(&a)[U], const f32x2(&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            acc[0] = mfma16(a[u][0], b[u][0], acc[0]);
+            acc[1] = mfma16(a[u][0], b[u][1], acc[1]);
+            acc[2] = mfma16(a[u][1], b[u][0], acc[2]);
+            acc[3] = mfma16(a[u][1], b[u][1], acc[3]);
+        }
+    };
+    load(0, a0, b0);
+    for (int s = 0; s < ksteps; s += 2 * U) {
+        const bool more1 = s + U < ksteps, more2 = s + 2 * U < ksteps;
+        if (more1) load(s + U, a1, b1);
+        compute(a0, b0);
+        if (more1) {
+            if (more2) load(s + 2 * U, a0, b0);
+            compute(a1, b1);
+        }
+    }
+    if (!nin2) return;
+    const int nt = p.ntype[seg];
+    // tile (u, t): D row 4kk + r <-> lane-row jA = 4kk + r of the A operand, i.e. m = m0 + 2 jA + u; column j <-> n0 + 2j + t
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + 2 * (4 * kk + r) + u;
+            if (m >= M) continue;
+            f32x2 o = {acc[2 * u][r], acc[2 * u + 1][r]};
+            if (p.nacts[seg]) {
+#pragma unroll
+                for (int t = 0; t < 2; t++) o[t] = neuron_grad(nt, o[t], nact[u][r][t], 0.f, p.na[seg], p.nb[seg]);
+            }
+            if (beta != 0.f) o += beta * cold[u][r];
+            *reinterpret_cast<f32x2*>(p.C[seg] + (size_t)m * p.N + n0 + 2 * j) = o;
+        }
+}
+
+bool fc_fprop_multi_usable(const float* const* W, const float* const* X, const int* K, int count, const float* Y, int M, int N) {
+    if (count < 1 || count > FCM_MAXSEG || M < 1 || N < 1 || (long)divup(M, 16) * divup(N, 16) > 4096) return false;
+    long total = 0;
+    for (int i = 0; i < count; i++) {
+        if (K[i] <= 0 || K[i] % 16 != 0 || !al16(W[i]) || !X[i]) return false;
+        total += K[i];
+    }
+    return total >= 16 && Y != nullptr;
+}
+
+int fc_fprop_multi_launch(const float* const* W, const float* const* X, const int* K, int count, const float* bias, float* Y, int M,
+                          int N, float beta, int neuron, float na, float nb, hipStream_t s) {
+    FcMultiParams p = {};
+    p.nseg = count;
+    p.totalSteps = 0;
+    for (int i = 0; i < count; i++) {
+        p.A[i] = W[i]; p.B[i] = X[i]; p.K[i] = K[i]; p.steps[i] = K[i] / 16;
+        p.totalSteps += p.steps[i];
+    }
+    for (int i = count; i < FCM_MAXSEG; i++) p.steps[i] = 1 << 30;
+    p.bias = bias; p.Y = Y; p.M = M; p.N = N; p.neuron = neuron; p.fa = na; p.fb = nb; p.fbeta = beta;
+    dim3 grid(divup(N, 16), divup(M, 16));
+    MCN_REQUIRE(grid.y <= 65535, "fcFpropMulti: grid too large");
+    hipLaunchKernelGGL((k_fc_fprop_multi<6>), grid, dim3(512), 0, s, p);
+    return MCN_LAUNCH_CHECK("fcFpropMulti");
+}
+
+bool fc_bprop_multi_usable(const float* const* W, float* const* dX, const int* Mi, int count, const float* dY, int K, int N) {
+    if (count < 1 || count > FCM_MAXSEG || K < 1 || N < 2 || N % 2 != 0 || !dY || ((uintptr_t)dY % 8) != 0) return false;
+    long tiles = 0;
+    for (int i = 0; i < count; i++) {
+        if (Mi[i] < 2 || Mi[i] % 2 != 0 || !W[i] || !dX[i] || ((uintptr_t)W[i] % 8) != 0 || ((uintptr_t)dX[i] % 8) != 0) return false;
+        tiles += divup(Mi[i], 32);
+    }
+    return tiles <= 65535 && K <= 4096;
+}
+
+int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi, const float* beta, const float* const* nacts,
+                          const int* ntype, const float* na, const float* nb, int count, const float* dY, int K, int N, hipStream_t s) {
+    FcMultiParams p = {};
+    p.nseg = count;
+    int tiles = 0;
+    for (int i = 0; i < count; i++) {
+        p.A[i] = W[i]; p.C[i] = dX[i]; p.K[i] = Mi[i]; p.steps[i] = divup(Mi[i], 32); p.beta[i] = beta[i];
+        p.nacts[i] = nacts ? nacts[i] : nullptr;
+        p.ntype[i] = ntype ? ntype[i] : MCN_NEURON_IDENT;
+        p.na[i] = na ? na[i] : 0.f;
+        p.nb[i] = nb ? nb[i] : 0.f;
+        if (p.nacts[i]) MCN_REQUIRE(((uintptr_t)p.nacts[i] % 8) == 0 && neuron_valid(p.ntype[i]), "fcBpropActsMulti: bad neuron operand");
+        tiles += p.steps[i];
+    }
+    for (int i = count; i < FCM_MAXSEG; i++) p.steps[i] = 1 << 30;
+    p.dY = dY; p.Kb = K; p.N = N;
+    dim3 grid(divup(N, 32), tiles);
+    hipLaunchKernelGGL((k_fc_bprop_multi<10>), grid, dim3(64), 0, s, p);
+    return MCN_LAUNCH_CHECK("fcBpropActsMulti");
+}
+
+MCN_API int mcn_fc_fprop_multi_supported(const float* const* weights, const float* const* inputs, const int* numInputs, int count,
+                                         const float* acts, int numOutputs, int numCases) {
+    return (weights && inputs && numInputs && fc_fprop_multi_usable(weights, inputs, numInputs, count, acts, numOutputs, numCases)) ? 1 : 0;
+}
+MCN_API int mcn_fc_fprop_multi(const float* const* weights, const float* const* inputs, const int* numInputs, int count,
+                               const float* biases, float* acts, int numOutputs, int numCases, int neuron, float neuronA, float neuronB,
+                               void* stream) {
+    MCN_REQUIRE(weights && inputs && numInputs && acts, "fcFpropMulti: null pointer");
+    MCN_REQUIRE(neuron_valid(neuron), "fcFpropMulti: bad neuron type %d", neuron);
+    MCN_REQUIRE(fc_fprop_multi_usable(weights, inputs, numInputs, count, acts, numOutputs, numCases),
+                "fcFpropMulti: unsupported shape (every input size must be a multiple of 16, at most %d inputs)", FCM_MAXSEG);
+    return fc_fprop_multi_launch(weights, inputs, numInputs, count, biases, acts, numOutputs, numCases, 0.f, neuron, neuronA, neuronB,
+                                 (hipStream_t)stream);
+}
+MCN_API int mcn_fc_bprop_acts_multi_supported(const float* const* weights, float* const* targets, const int* numInputs, int count,
+                                              const float* actsGrad, int numOutputs, int numCases) {
+    return (weights && targets && numInputs && fc_bprop_multi_usable(weights, targets, numInputs, count, actsGrad, numOutputs, numCases)) ? 1 : 0;
+}
+MCN_API int mcn_fc_bprop_acts_multi(const float* const* weights, float* const* targets, const int* numInputs, const float* scaleTargets,
+                                    const float* const* neuronActs, const int* neuronTypes, const float* neuronA, const float* neuronB,
+                                    int count, const float* actsGrad, int numOutputs, int numCases, void* stream) {
+    MCN_REQUIRE(weights && targets && numInputs && scaleTargets && actsGrad, "fcBpropActsMulti: null pointer");
+    MCN_REQUIRE(fc_bprop_multi_usable(weights, targets, numInputs, count, actsGrad, numOutputs, numCases),
+                "fcBpropActsMulti: unsupported shape (even input sizes and case count, at most %d inputs)", FCM_MAXSEG);
+    return fc_bprop_multi_launch(weights, targets, numInputs, scaleTargets, neuronActs, neuronTypes, neuronA, neuronB, count, actsGrad,
+                                 numOutputs, numCases, (hipStream_t)stream);
+}

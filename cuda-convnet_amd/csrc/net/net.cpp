@@ -363,8 +363,37 @@ size_t FCLayer::workspaceBytes(int maxCases) {
     return b;
 }
 
+void FCLayer::planMulti() {
+    multiShapes = _prev.size() >= 2 && _prev.size() <= 4 && getenv("MCN_NO_FC_MULTI") == nullptr;  // (A/B switch)
+    for (size_t a = 0; a < _prev.size(); a++) {
+        multiShapes = multiShapes && _prev[a]->outputs() % 16 == 0;
+        for (size_t b = a + 1; b < _prev.size(); b++) multiShapes = multiShapes && _prev[a] != _prev[b];
+    }
+    neuronAbove.assign(_prev.size(), nullptr);
+    _bwdDone.assign(_prev.size(), 0);
+}
+
 void FCLayer::fpropActs(int i, float scaleTargets, PassType) {
     const int n = _net->numCases(), I = _prev[i]->outputs();
+    if (multiShapes && _net->fusion() && _actsTarget < 0) {
+        // every input in one launch (the reference: one sgemm per input, layer.cu:355-360)
+        if (i == 0) {
+            const float* W[4];
+            const float* X[4];
+            int K[4];
+            const int cnt = (int)_prev.size();
+            for (int k = 0; k < cnt; k++) { W[k] = _weights[k]->W(); X[k] = _inputs[k]; K[k] = _prev[k]->outputs(); }
+            _fwdAllDone = mcn_fc_fprop_multi_supported(W, X, K, cnt, _acts, _outputs, n) != 0;
+            if (_fwdAllDone) {
+                chk(mcn_fc_fprop_multi(W, X, K, cnt, _biases->W(), _acts, _outputs, n, fusedNeuron ? fusedNeuron->spec.type : MCN_NEURON_IDENT,
+                                       fusedNeuron ? fusedNeuron->spec.a : 0.f, fusedNeuron ? fusedNeuron->spec.b : 0.f, _net->stream()),
+                    "fc fprop (all inputs)");
+                return;
+            }
+        } else if (_fwdAllDone) {
+            return;
+        }
+    }
     if (scaleTargets == 0 && softmaxBelow && _net->fusion() && softmaxBelow->part.p &&
         mcn_gemm_softmax_part_supported(_weights[i]->W(), _inputs[i], _acts, _outputs, n, I)) {
         // classifier layer: the product also leaves stage 1 of the softmax that follows (no pass of its own over the acts)
@@ -374,7 +403,7 @@ void FCLayer::fpropActs(int i, float scaleTargets, PassType) {
                                               _net->stream()), "fc fprop + softmax stage 1");
         softmaxBelow->partReady = true;
     } else if (scaleTargets == 0) {
-        const bool fuse = fusedNeuron && _prev.size() == 1;
+        const bool fuse = fusedNeuron && _prev.size() == 1;  // (several inputs: the neuron follows the last product below)
         chk(mcn_gemm_bias_neuron(_weights[i]->W(), _inputs[i], _biases->W(), _acts, _outputs, n, I, 0.f,
                                  fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fuse ? fusedNeuron->spec.a : 0.f,
                                  fuse ? fusedNeuron->spec.b : 0.f, _net->workspace(), _net->workspaceBytes(), _net->stream()),
@@ -383,12 +412,51 @@ void FCLayer::fpropActs(int i, float scaleTargets, PassType) {
         chk(mcn_gemm(_weights[i]->W(), _inputs[i], _acts, _outputs, n, I, 0, 0, 1.f, scaleTargets, _net->workspace(),
                      _net->workspaceBytes(), _net->stream()), "fc fprop");
     }
+    if (fusedNeuron && _prev.size() > 1 && i == (int)_prev.size() - 1)  // fused by plan, but this shape took the per-input path
+        chk(mcn_neuron_fwd(_acts, _acts, (size_t)_outputs * n, fusedNeuron->spec.type, fusedNeuron->spec.a, fusedNeuron->spec.b, _net->stream()),
+            "fc neuron");
 }
 
 void FCLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {
     const int n = _net->numCases(), I = _prev[i]->outputs();
-    chk(mcn_gemm(_weights[i]->W(), v, _prev[i]->getActsGrad(), I, n, _outputs, 1, 0, 1.f, scaleTargets, _net->workspace(),
-                 _net->workspaceBytes(), _net->stream()), "fc bprop acts");
+    if (_bwdDone[i]) {  // written by the all-inputs launch of an earlier input of this pass
+        _bwdDone[i] = 0;
+        return;
+    }
+    if (multiShapes && _net->fusion() && _actsGradTarget < 0) {
+        // every gradient-consuming input in one launch (the reference: one sgemm per input, layer.cu:362-366)
+        const float* W[4];
+        float* T[4];
+        const float* NA[4];
+        int K[4], NT[4], idx[4];
+        float sT[4], na[4], nb[4];
+        int cnt = 0;
+        for (int k = i; k < (int)_prev.size(); k++) {
+            if (!_prev[k]->isGradConsumer()) continue;
+            W[cnt] = _weights[k]->W();
+            T[cnt] = _prev[k]->getActsGrad();
+            K[cnt] = _prev[k]->outputs();
+            sT[cnt] = k == i ? scaleTargets : (_prev[k]->rcvdB() > 0 ? 1.f : 0.f);
+            NeuronLayer* r = neuronAbove[k];
+            NA[cnt] = r ? r->getActs() : nullptr;
+            NT[cnt] = r ? r->spec.type : MCN_NEURON_IDENT;
+            na[cnt] = r ? r->spec.a : 0.f;
+            nb[cnt] = r ? r->spec.b : 0.f;
+            idx[cnt++] = k;
+        }
+        if (cnt >= 2 && mcn_fc_bprop_acts_multi_supported(W, T, K, cnt, v, _outputs, n)) {
+            for (int c = 1; c < cnt; c++) _prev[idx[c]]->awaitSeed();
+            chk(mcn_fc_bprop_acts_multi(W, T, K, sT, NA, NT, na, nb, cnt, v, _outputs, n, _net->stream()), "fc bprop acts (all inputs)");
+            for (int c = 1; c < cnt; c++) _bwdDone[idx[c]] = 1;
+            return;
+        }
+    }
+    float* tgt = _prev[i]->getActsGrad();
+    chk(mcn_gemm(_weights[i]->W(), v, tgt, I, n, _outputs, 1, 0, 1.f, scaleTargets, _net->workspace(), _net->workspaceBytes(),
+                 _net->stream()), "fc bprop acts");
+    if (NeuronLayer* r = neuronAbove[i])  // its gradient is this layer's job (buildFusions); scaleTargets is 0 by construction
+        chk(mcn_neuron_bwd(tgt, r->getActs(), r->getActs(), tgt, (size_t)I * n, r->spec.type, r->spec.a, r->spec.b, 0, _net->stream()),
+            "fc bprop acts: neuron grad");
 }
 
 void FCLayer::bpropBiases(float* v, PassType pt) {
@@ -767,8 +835,11 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
     // stream right away and is the FIRST gradient its input receives this pass; the backward chain then accumulates onto it
     // (a + b == b + a: same bits as the reference order, layer.cu:1073-1082 after fc6's) instead of stopping for it.
     float* early = nullptr;
-    static const bool noEarly = getenv("MCN_NO_EARLY_L2SN") != nullptr;  // (A/B switch)
-    if (!noEarly && !gather && !_net->dataParallel() && pt == PASS_TRAIN && _coeff != 0 && _net->fusion() && _prev[1]->isGradConsumer() &&
+    // Opt-in (MCN_EARLY_L2SN=1): measured 20 us per step SLOWER on DeepID2 -- the cost kernel starts ~16 us after the fork
+    // (thread hand-over + cross-stream wait) and runs 11 us, so the first backward kernel, which then has to wait for the
+    // seeded matrix, stalls; in the reference order the wait comes one kernel later and is covered.
+    static const bool earlyOn = getenv("MCN_EARLY_L2SN") != nullptr;
+    if (earlyOn && !gather && !_net->dataParallel() && pt == PASS_TRAIN && _coeff != 0 && _net->fusion() && _prev[1]->isGradConsumer() &&
         _prev[1]->rcvdB() == 0)
         early = _prev[1]->getActsGrad();
     const float coeff = _coeff;
@@ -994,6 +1065,27 @@ void ConvNet::buildFusions() {
                     r->fwdFused = true;
                 }
             }
+        }
+        // FC layer with several inputs: all of them in one launch per direction; the forward neuron and, per input, the
+        // gradient of a neuron layer feeding only this layer go into the epilogues
+        if (auto* fc = dynamic_cast<FCLayer*>(up.get())) {
+            fc->planMulti();
+            if (fc->multiShapes && fc->next().size() == 1 && !fc->fusedNeuron) {
+                auto* r = dynamic_cast<NeuronLayer*>(fc->next()[0]);
+                if (r && r->actsTarget() == 0 && r->prev().size() == 1) {
+                    fc->fusedNeuron = r;
+                    r->fwdFused = true;
+                }
+            }
+            if (fc->multiShapes)
+                for (size_t k = 0; k < fc->prev().size(); k++) {
+                    auto* r = dynamic_cast<NeuronLayer*>(fc->prev()[k]);
+                    if (r && !r->bwdFused && r->actsGradTarget() == 0 && r->numGradProducersNext() == 1 && r->next().size() == 1 &&
+                        r->prev().size() == 1 && r->spec.fusableGrad() && r->isGradConsumer()) {
+                        fc->neuronAbove[k] = r;
+                        r->bwdFused = true;
+                    }
+                }
         }
         // classifier layer directly under a softmax: stage 1 of the softmax in the epilogue of the forward product
         // (possibly through the neuron layer fused into that product above: `neuron=ident` in the DeepID cfgs)
@@ -1340,7 +1432,10 @@ void ConvNet::deferLateWork(std::function<void()> fn) {
         fn();
         return;
     }
-    if (dataParallel()) {  // there the main stream's tail is the hand-over of the last bucket: keep the costs on the side stream
+    // (measured: on the side stream right after the softmax instead, MCN_SIDE_COST=1, the step is 0-3 us slower -- the end of
+    // a step is bound by the side stream's gradient tail as much as by the main stream)
+    static const bool sideCost = getenv("MCN_SIDE_COST") != nullptr;
+    if (dataParallel() || sideCost) {  // data parallel: the main stream's tail is the hand-over of the last bucket
         deferSideWork(std::move(fn), 0);
         return;
     }

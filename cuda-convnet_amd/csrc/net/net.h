@@ -210,11 +210,17 @@ class FCLayer : public WeightLayer {
     FCLayer(ConvNet* net, const Params& p);
     size_t workspaceBytes(int maxCases) override;
     SoftmaxLayer* softmaxBelow = nullptr;  // the only consumer is a softmax: the forward product leaves its stage-1 partials
+    // several inputs (DeepID's fc5): one launch per direction for all of them (mcn_fc_fprop_multi / mcn_fc_bprop_acts_multi)
+    bool multiShapes = false;                    // every input size a multiple of 16, at most 4 distinct input layers
+    std::vector<NeuronLayer*> neuronAbove;       // per input: neuron layer whose gradient the backward-data product applies
+    void planMulti();
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
     void bpropBiases(float* v, PassType) override;
     void bpropWeights(float* v, int, PassType) override;
+    bool _fwdAllDone = false;
+    std::vector<char> _bwdDone;
 };
 
 class LocalLayer : public WeightLayer {

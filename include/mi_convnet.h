@@ -234,6 +234,24 @@ int mcn_gemm_softmax_part_supported(const float* A, const float* B, const float*
 int mcn_gemm_bias_neuron_softmax_part(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
                                       int neuron, float neuronA, float neuronB, void* softmaxPart, size_t softmaxPartBytes,
                                       void* stream);
+/* FCLayer::fpropActs over ALL inputs of the layer in one launch (layer.cu:355-360 issues one addProduct per input; DeepID's
+ * fc5 has two): acts (numOutputs, numCases) = sum_i weights[i] (numOutputs x numInputs[i], row-major) * inputs[i]
+ * (numInputs[i], numCases) + biases[row], then the neuron.  The pointer arrays are host arrays of `count` entries.
+ * Shapes: every numInputs[i] a multiple of 16, weights 16-byte aligned, count <= 4 (see ..._supported). */
+int mcn_fc_fprop_multi_supported(const float* const* weights, const float* const* inputs, const int* numInputs, int count,
+                                 const float* acts, int numOutputs, int numCases);
+int mcn_fc_fprop_multi(const float* const* weights, const float* const* inputs, const int* numInputs, int count,
+                       const float* biases, float* acts, int numOutputs, int numCases, int neuron, float neuronA, float neuronB,
+                       void* stream);
+/* FCLayer::bpropActs for ALL inputs in one launch (layer.cu:362-366): targets[i] (numInputs[i], numCases) =
+ * scaleTargets[i]*targets[i] + g(weights[i]^T * actsGrad), where g is the identity or, when neuronActs[i] is given, the
+ * gradient of the neuron that produced input i from its output neuronActs[i] (NeuronLayer::bpropActs layer.cu:245, for
+ * neurons whose gradient needs their output only).  neuronActs / neuronTypes / neuronA / neuronB may be NULL. */
+int mcn_fc_bprop_acts_multi_supported(const float* const* weights, float* const* targets, const int* numInputs, int count,
+                                      const float* actsGrad, int numOutputs, int numCases);
+int mcn_fc_bprop_acts_multi(const float* const* weights, float* const* targets, const int* numInputs, const float* scaleTargets,
+                            const float* const* neuronActs, const int* neuronTypes, const float* neuronA, const float* neuronB,
+                            int count, const float* actsGrad, int numOutputs, int numCases, void* stream);
 /* addVector (nvmatrix.cu:652-690): mat(rows x cols) += scale*vec; perRow=1: vec[rows], 0: vec[cols]. */
 int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream);
 /* addSum (nvmatrix.cu:896-906 -> _aggregate :700-805): tgt = scaleThis*tgt + scaleSum*sum(mat, axis).

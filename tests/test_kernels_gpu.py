@@ -473,6 +473,62 @@ def test_fc_forward_with_softmax_partials(O_, I, N):
     close(d_p2.numpy(), got_p, rtol=1e-5, what='fused vs stand-alone softmax')
 
 
+def ptr_array(bufs):
+    return (C.c_void_p * len(bufs))(*[b.ptr if b is not None else None for b in bufs])
+
+
+@pytest.mark.parametrize('O_,Is,N', [(160, [1024, 1200], 128), (160, [1024, 1200], 72), (160, [1024, 1200], 33), (512, [2048, 3200], 128),
+                                     (27, [160], 128), (160, [16, 32, 48, 160], 130)])
+def test_fc_fprop_all_inputs_in_one_launch(O_, Is, N):
+    """FCLayer::fpropActs over every input at once (layer.cu:355-360) == the per-input GEMMs of the oracle + bias + neuron."""
+    rng = np.random.default_rng(181)
+    Ws = [mk(rng, O_, I, scale=0.02) for I in Is]
+    Xs = [mk(rng, I, N) for I in Is]
+    b = mk(rng, O_, scale=0.1)
+    want = O.gemm(Ws[0], Xs[0], O_, N, Is[0])
+    for W, X, I in zip(Ws[1:], Xs[1:], Is[1:]):
+        want = O.gemm(W, X, O_, N, I, beta=1.0, Cmat=want)
+    O.add_vector(want, b, O_, N, True)
+    want = O.neuron_fwd(want, 'relu')
+    dW, dX = [dev(w) for w in Ws], [dev(x) for x in Xs]
+    d_y = dev_empty((O_, N), np.nan)
+    wa, xa, ka = ptr_array(dW), ptr_array(dX), (C.c_int * len(Is))(*Is)
+    assert capi.lib().raw('mcn_fc_fprop_multi_supported')(wa, xa, ka, len(Is), d_y.ptr, O_, N) == 1
+    call('mcn_fc_fprop_multi', wa, xa, ka, len(Is), dev(b), d_y, O_, N, 1, 0.0, 0.0, None)
+    close(d_y.numpy(), want, what='fc forward, %d inputs' % len(Is))
+
+
+@pytest.mark.parametrize('O_,Is,N', [(160, [1024, 1200], 128), (160, [1024, 1200], 72), (512, [2048, 3200], 128), (160, [1024], 2),
+                                     (23, [160, 30], 128)])
+def test_fc_bprop_acts_all_inputs_in_one_launch(O_, Is, N):
+    """FCLayer::bpropActs for every input at once (layer.cu:362-366); input 0 additionally through the gradient of the
+    relu that produced it (NeuronLayer::bpropActs layer.cu:245), the last input accumulating (scaleTargets = 1)."""
+    rng = np.random.default_rng(182)
+    Ws = [mk(rng, O_, I, scale=0.02) for I in Is]
+    dY = mk(rng, O_, N)
+    acts0 = np.maximum(mk(rng, Is[0], N), 0)
+    t0 = [mk(rng, I, N) for I in Is]
+    betas = [0.0] * len(Is)
+    betas[-1] = 1.0 if len(Is) > 1 else 0.0
+    wants = []
+    for i, (W, I) in enumerate(zip(Ws, Is)):
+        g = O.gemm(W, dY, I, N, O_, ta=True)
+        if i == 0:
+            g = O.neuron_bwd(g, acts0, acts0, 'relu')
+        wants.append((np.float32(betas[i]) * t0[i] + g).astype(np.float32))
+    dW, dT = [dev(w) for w in Ws], [dev(t) for t in t0]
+    d_a = dev(acts0)
+    wa, ta_, ka = ptr_array(dW), ptr_array(dT), (C.c_int * len(Is))(*Is)
+    na = ptr_array([d_a] + [None] * (len(Is) - 1))
+    nt = (C.c_int * len(Is))(*([1] + [0] * (len(Is) - 1)))
+    zf = (C.c_float * len(Is))(*([0.0] * len(Is)))
+    d_dy = dev(dY)
+    assert capi.lib().raw('mcn_fc_bprop_acts_multi_supported')(wa, ta_, ka, len(Is), d_dy.ptr, O_, N) == 1
+    call('mcn_fc_bprop_acts_multi', wa, ta_, ka, (C.c_float * len(Is))(*betas), na, nt, zf, zf, len(Is), d_dy, O_, N, None)
+    for i in range(len(Is)):
+        close(dT[i].numpy(), wants[i], what='dX[%d]' % i)
+
+
 def test_gemm_odd_sizes():
     rng = np.random.default_rng(19)
     for M, N, K, ta, tb in [(37, 45, 51, 0, 0), (37, 45, 51, 1, 0), (37, 45, 51, 0, 1), (1, 1, 1, 0, 0), (300, 130, 2049, 0, 0)]:
