@@ -33,14 +33,14 @@ struct AVec { float v[FV]; };
 // k-steps (of 4) loaded per batch: all loads of a batch are issued before its MFMAs and the next batch is
 // prefetched into a second register set while the current one is multiplied (the shapes here have at most a
 // few waves per SIMD, so load latency has to be hidden inside the wave)
-template <int FV, int NQ, int U, bool KSPLIT, bool VECN>
-__global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
+template <int FV, int NQ, int U, bool KSPLIT, bool VECN, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_filter_acts(const FwdParams p) {
     extern __shared__ int tbl[];
     constexpr int KB = 4 * U, T = FV * NQ * 4;
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int K = fc * fp, Kpad = (K + KB - 1) / KB * KB, M = p.mY * p.mX;
     const int imgPixels = p.imgY * p.imgX;
-    for (int k = threadIdx.x; k < Kpad; k += 256) {
+    for (int k = threadIdx.x; k < Kpad; k += 64 * NW) {
         if (k < K) {
             const int c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
             tbl[2 * k] = c * imgPixels + fy * p.imgX + fx;
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    // KSPLIT: the four waves of the block share one module and take its k-batches round-robin (summed
-    // through LDS below); otherwise each wave owns its own module.
+    // KSPLIT: the NW waves of the block share one module and take its k-batches round-robin (summed
+    // through LDS below); otherwise each of four waves owns its own module.
     const int m = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
     if (!KSPLIT && m >= M) return;
     const int n0 = blockIdx.x * (64 * NQ);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
 #pragma unroll
                     for (int t = 0; t < 4; t++) acc[u][q * 4 + t] = mfma16(a[s].v[u], b[s][q][t], acc[u][q * 4 + t]);
     };
-    const int kFirst = KSPLIT ? wave * KB : 0, kStep = KSPLIT ? 4 * KB : KB;
+    const int kFirst = KSPLIT ? wave * KB : 0, kStep = KSPLIT ? NW * KB : KB;
     if (kFirst < K) load(kFirst, a0, b0);
     for (int kb = kFirst; kb < K; kb += 2 * kStep) {
         const bool more1 = kb + kStep < K, more2 = kb + 2 * kStep < K;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
 #pragma unroll
     for (int g = 0; g < FV * NQ; g++) mine[g] = true;
     if (KSPLIT) {
-        // fixed-order sum of the four waves' accumulators; group g = u*NQ + q is finished and stored by wave g % 4
+        // fixed-order sum of the NW waves' accumulators; group g = u*NQ + q is finished and stored by wave g % NW
         __syncthreads();
         f32x4* red = reinterpret_cast<f32x4*>(tbl);
 #pragma unroll
@@ -151,13 +151,17 @@ __global__ __launch_bounds__(256) void k_filter_acts(const FwdParams p) {
         for (int u = 0; u < FV; u++)
 #pragma unroll
             for (int q = 0; q < NQ; q++) {
-                mine[u * NQ + q] = ((u * NQ + q) & 3) == wave;
+                mine[u * NQ + q] = ((u * NQ + q) % NW) == wave;
                 if (mine[u * NQ + q]) {
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int tile = u * NQ * 4 + q * 4 + t;
-                        acc[u][q * 4 + t] = (red[(0 * T + tile) * 64 + lane] + red[(1 * T + tile) * 64 + lane]) +
-                                            (red[(2 * T + tile) * 64 + lane] + red[(3 * T + tile) * 64 + lane]);
+                        f32x4 sum = (red[(0 * T + tile) * 64 + lane] + red[(1 * T + tile) * 64 + lane]) +
+                                    (red[(2 * T + tile) * 64 + lane] + red[(3 * T + tile) * 64 + lane]);
+                        if (NW == 8)
+                            sum += (red[(4 * T + tile) * 64 + lane] + red[(5 * T + tile) * 64 + lane]) +
+                                   (red[(6 * T + tile) * 64 + lane] + red[(7 * T + tile) * 64 + lane]);
+                        acc[u][q * 4 + t] = sum;
                     }
                 }
             }
@@ -376,6 +380,16 @@ static void launch_fast2(const FwdParams& p, dim3 grid, size_t lds, hipStream_t 
 
 template <int FV, int NQ, int U>
 static void launch_fwd3(const FwdParams& p, dim3 grid, size_t lds, bool vecn, bool ksplit, hipStream_t s) {
+    if (ksplit && vecn && p.mw >= 8) {  // (mw doubles as wave count + batch size of the split form: 8 + U)
+        if constexpr (NQ == 1 && U <= 8 && FV <= 3) {
+            const int u8 = p.mw - 8;
+            if (u8 == 9) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 9, true, true, 8>), grid, dim3(512), lds, s, p);
+            else if (u8 == 6) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 6, true, true, 8>), grid, dim3(512), lds, s, p);
+            else if (u8 == 8) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 8, true, true, 8>), grid, dim3(512), lds, s, p);
+            else hipLaunchKernelGGL((k_filter_acts<FV, NQ, 4, true, true, 8>), grid, dim3(512), lds, s, p);
+            return;
+        }
+    }
     if (ksplit) {
         if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, true>), grid, dim3(256), lds, s, p);
         else hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, false>), grid, dim3(256), lds, s, p);
@@ -488,13 +502,24 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
         if (waves(FV, NQ) < 1024 && NQ == 2) NQ = 1;
         while (waves(FV, NQ) < 1024 && FV > 1) FV = best_fv(FV - 1);
     }
-    const int U = fwd_batch(FV, NQ, K), KB = 4 * U;
+    int U = fwd_batch(FV, NQ, K);
+    // split form with 8 waves and batches of 4 k-steps: a wave's chain of dependent round trips is what a launch this small
+    // costs (local3: 200 workgroups, K = 288 -> 18 batches over 8 waves; measured 11.5 -> see DESIGN.md)
+    static const bool wide = getenv("MCN_FA_NW4") == nullptr;  // (A/B switch)
+    const bool eight = ksplit && vecn && wide && U <= 8 && K >= 128 && FV <= 3;
+    if (eight) {
+        // batch = a wave's whole share of K when that fits the registers (one round trip per wave), else 8 / 4
+        const int share = divup(divup(K, 4), 8);
+        U = share <= 4 ? 4 : share <= 6 ? 6 : share <= 9 ? 9 : (divup(K, 4) % 64 == 0 ? 8 : 9);
+        p.mw = 8 + U;
+    }
+    const int KB = 4 * U;
     if (K % KB != 0) p.check = 1;  // the padded k of the last batch must load zeros
     dim3 grid(divup(N, 64 * NQ), ksplit ? M : divup(M, 4), F / (16 * FV));
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "filterActs: grid too large");
     size_t lds = (size_t)divup(K, KB) * KB * 8;
-    if (ksplit) lds = std::max(lds, (size_t)4 * FV * NQ * 4 * 64 * 16);
-    MCN_REQUIRE(lds <= 64 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
+    if (ksplit) lds = std::max(lds, (size_t)(eight ? 8 : 4) * FV * NQ * 4 * 64 * 16);
+    MCN_REQUIRE(lds <= (eight ? 128 : 64) * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
     hipStream_t s = (hipStream_t)stream;
     switch (FV) {
         case 4: launch_fwd1<4>(p, NQ, U, grid, lds, vecn, ksplit, s); break;
