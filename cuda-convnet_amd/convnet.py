@@ -22,6 +22,18 @@ from . import CFG_DIR, layer as layer_mod
 from .data import SyntheticDataProvider, shard_for_rank
 
 
+class _CheckpointUnpickler(pickle.Unpickler):
+    _ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
+                ('numpy', 'dtype'), ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'),
+                ('numpy._core.numeric', '_frombuffer'), ('numpy.core.numeric', '_frombuffer'), ('builtins', 'bytearray'),
+                ('collections', 'OrderedDict')}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError('checkpoint refers to %s.%s: not a plain weights checkpoint' % (module, name))
+
+
 def import_native():
     try:
         from . import _ConvNet
@@ -149,8 +161,34 @@ class ConvNet:
 
     @staticmethod
     def load_state(path):
-        with open(path, 'rb') as f:  # only files written by save_state above
-            return pickle.load(f)
+        """Reads a checkpoint written by save_state.  A checkpoint is nested dicts / lists / tuples of numbers, strings
+        and numpy arrays, so the unpickler admits exactly that: numpy's array and dtype reconstructors and nothing else
+        (an unrestricted pickle.load would run whatever a file from an untrusted source asks for)."""
+        with open(path, 'rb') as f:
+            return _CheckpointUnpickler(f).load()
+
+    def write_features_mat(self, layer_name, feature_path, num_batches=None):
+        """shownet.py:238-259 (do_write_features): one MATLAB file `data_batch_<n>` = {'feats': (numCases, numFeatures)} per
+        test batch, the next batch fetched while the current one computes.  Returns the paths written."""
+        import scipy.io
+        os.makedirs(feature_path, exist_ok=True)
+        idx = layer_mod.layer_index(self.layers, layer_name)
+        num_ftrs = self.layers[idx]['outputs']
+        paths = []
+        next_data = self.test_data_provider.get_next_batch()
+        b1 = next_data[1]
+        while True:
+            batch, data = next_data[1], next_data[2]
+            ftrs = np.zeros((data[0].shape[1], num_ftrs), dtype=np.float32)
+            self.libmodel.startFeatureWriter(list(data) + [ftrs], idx)
+            next_data = self.test_data_provider.get_next_batch()  # load the next batch while the current one is computing
+            self.libmodel.finishBatch()
+            path_out = os.path.join(feature_path, 'data_batch_%d.mat' % batch)
+            scipy.io.savemat(path_out, {'feats': ftrs})
+            paths.append(path_out)
+            if next_data[1] == b1 or (num_batches is not None and len(paths) >= num_batches):
+                break
+        return paths
 
     def close(self):
         self.libmodel.destroyModel()

@@ -8,6 +8,7 @@
 //   destroyModel()                       stop the worker thread and release the device
 //   startSteps(n, test=0, profile=0)     n minibatch steps cycling over the resident batch (finishBatch collects)
 //   getProfile()                         per-operation device time of the last profiled startSteps
+//   getCommLog() / getGradSegments()     the data-parallel exchange as it was issued, and the arena layout (tests)
 // Differences from the reference that a caller can observe: errors raise RuntimeError
 // instead of exit(1)/assert; checkGradients returns its per-matrix results instead of
 // printing and calling exit(0); the GIL is released while a call blocks.
@@ -332,6 +333,29 @@ static PyObject* initDataParallel(PyObject*, PyObject* args) {
     return Py_BuildValue("i", 0);
 }
 
+// the data-parallel plan as it ran: [(kind, arena offset, count)] since the last call, and the arena layout it refers to
+static PyObject* getCommLog(PyObject*, PyObject*) {
+    if (!needModel()) return nullptr;
+    PyObject* out = PyList_New(0);
+    for (const ConvNet::CommRec& r : model->takeCommLog()) {
+        PyObject* t = Py_BuildValue("(snn)", r.kind == 0 ? "allreduce" : "allgather", (Py_ssize_t)r.offset, (Py_ssize_t)r.count);
+        PyList_Append(out, t);
+        Py_DECREF(t);
+    }
+    return out;
+}
+
+static PyObject* getGradSegments(PyObject*, PyObject*) {
+    if (!needModel()) return nullptr;
+    PyObject* out = PyList_New(0);
+    for (const ConvNet::SegmentInfo& s : model->gradSegments()) {
+        PyObject* t = Py_BuildValue("(snn)", s.layer.c_str(), (Py_ssize_t)s.begin, (Py_ssize_t)s.end);
+        PyList_Append(out, t);
+        Py_DECREF(t);
+    }
+    return Py_BuildValue("Nn", out, (Py_ssize_t)model->bucketFloats());
+}
+
 static PyMethodDef methods[] = {
     {"initModel", initModel, METH_VARARGS, "initModel(layers, minibatchSize, deviceID)"},
     {"startBatch", startBatch, METH_VARARGS, "startBatch(data, test=0): asynchronous; data == [] uses the batch left by loadBatch"},
@@ -345,6 +369,8 @@ static PyMethodDef methods[] = {
     {"getProfile", getProfile, METH_NOARGS, "getProfile() -> {operation: (count, total device ms)} of the last profiled startSteps"},
     {"commUniqueId", commUniqueId, METH_NOARGS, "commUniqueId() -> 128 bytes"},
     {"initDataParallel", initDataParallel, METH_VARARGS, "initDataParallel(rank, worldSize, uniqueId, force=0)"},
+    {"getCommLog", getCommLog, METH_NOARGS, "getCommLog() -> [(kind, arenaOffset, count)] issued since the last call (data parallel)"},
+    {"getGradSegments", getGradSegments, METH_NOARGS, "getGradSegments() -> ([(layer, begin, end)] in arena order, bucketFloats)"},
     {"destroyModel", destroyModel, METH_NOARGS, "destroyModel()"},
     {nullptr, nullptr, 0, nullptr}};
 

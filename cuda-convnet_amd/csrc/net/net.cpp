@@ -276,6 +276,14 @@ WeightLayer::WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortr
     if (hW.size() != hInc.size() || hW.size() != epsW.size() || hW.size() != momW.size() || hW.size() != wc.size() ||
         hW.size() != srcL.size() || hW.size() != srcM.size())
         throw NetError("layer '" + _name + "': weight parameter lists differ in length");
+    // Weight sharing (`weightSource`, weights.cuh:59-68) is parsed but refused here: no BASELINE config uses it (only an archival
+    // siamese cfg under layers/), there is no parity evidence for it, and the reference's own accumulate rule for a shared FC /
+    // local matrix overwrites all but the last contribution (layer.cu:378, :554).  The sharing constructor below stays for the
+    // day it is covered; until then a net that asks for it fails loudly instead of training on unverified gradients.
+    for (size_t i = 0; i < hW.size(); i++)
+        if (srcL[i] >= 0 && getenv("MCN_ALLOW_WEIGHT_SHARING") == nullptr)
+            throw NetError("layer '" + _name + "': weight sharing (weightSource) is not supported by this build (no parity coverage; "
+                           "see DESIGN.md section 8)");
     for (size_t i = 0; i < hW.size(); i++) {
         if (srcL[i] == net->numLayers()) {  // current layer (layer.cu:280-281)
             _weights.emplace_back(new Weights(*_weights.at(srcM[i]), (float)epsW[i]));
@@ -1399,11 +1407,31 @@ void ConvNet::waitExchangeSubmitted(long ticket) {
     if (ticket > 0) _commSub.wait(ticket);
 }
 
+void ConvNet::logComm(int kind, size_t offset, size_t count) {
+    std::lock_guard<std::mutex> lk(_logMutex);
+    if (_commLog.size() < 65536) _commLog.push_back({kind, offset, count});
+}
+
+std::vector<ConvNet::CommRec> ConvNet::takeCommLog() {
+    std::lock_guard<std::mutex> lk(_logMutex);
+    std::vector<CommRec> out;
+    out.swap(_commLog);
+    return out;
+}
+
+std::vector<ConvNet::SegmentInfo> ConvNet::gradSegments() {
+    std::vector<SegmentInfo> out;
+    for (const Segment& s : _segments) out.push_back({s.layer->name(), s.begin, s.end});
+    return out;
+}
+
 void ConvNet::gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
     chk(mcn_comm_group_begin(), "group begin");
     chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
     chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
     chk(mcn_comm_group_end(), "group end");
+    logComm(1, 0, countPerRank);
+    logComm(1, 0, countPerRank);
 }
 
 void ConvNet::joinExchange() {
@@ -1627,6 +1655,7 @@ void ConvNet::flushBuckets(bool force) {
         if (evSide) chk(mcn_stream_wait_event(_commStream, evSide), "wait event");
         const auto t0 = std::chrono::steady_clock::now();
         chk(mcn_allreduce_sum(_comm, buf, count, _commStream), "all-reduce");
+        logComm(0, (size_t)(buf - _gradArena.p), count);
         _rcclCallNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         _rcclCalls++;
     });
@@ -1657,6 +1686,8 @@ void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, f
         chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
         chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
         chk(mcn_comm_group_end(), "group end");
+        logComm(1, 0, countPerRank);
+        logComm(1, 0, countPerRank);
         chk(mcn_event_record(_evGather, _commStream), "event record");
     });
 }

@@ -573,6 +573,13 @@ class ConvNet {
     void gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // exchange thread only
     void joinExchange();
     void exchangeWorkJoined() { _exchangeWorkPending = false; }
+    // data-parallel plan, for tests without 8 GPUs: the collectives in the order the exchange thread issued them
+    // (kind 0 all-reduce over [offset, offset + count) of the gradient arena, kind 1 all-gather of count floats per rank)
+    struct CommRec { int kind; size_t offset, count; };
+    std::vector<CommRec> takeCommLog();
+    struct SegmentInfo { std::string layer; size_t begin, end; };
+    std::vector<SegmentInfo> gradSegments();
+    size_t bucketFloats() const { return _bucketFloats; }
     void setFusion(bool on) { _fusion = on; }
     bool fusion() const { return _fusion; }
     bool profiling() const { return _profiling; }
@@ -642,6 +649,9 @@ class ConvNet {
     size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
     size_t _bucketFloats = 1 << 20;
     bool _commPending = false;
+    std::mutex _logMutex;
+    std::vector<CommRec> _commLog;
+    void logComm(int kind, size_t offset, size_t count);
 
     // step graphs
     struct StepGraph { void* exec = nullptr; std::vector<float*> data; int numCases = 0; int nodes = 0; };

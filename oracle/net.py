@@ -604,6 +604,32 @@ class OracleNet:
             out[s:s + mini[0].shape[1]] = self.layers[layer_idx].acts.T
         return out
 
+    def run_multiview(self, data, num_views, logreg_idx):
+        """MultiviewTestWorker::run (worker.cu:142-174): the batch holds num_views views of numCases/num_views real cases,
+        view-major; the softmax outputs of the views are averaged and the logreg cost is taken of the average.  The
+        other cost layers report what their last view left (ConvNet::getCost adds every cost layer, convnet.cu:240-245)."""
+        n_total = data[0].shape[1]
+        assert n_total % num_views == 0
+        real = n_total // num_views
+        mb = self.minibatch_size
+        logreg = self.layers[logreg_idx]
+        tot, cases = {}, 0
+        for i in range((real + mb - 1) // mb):
+            sm = None
+            for v in range(num_views):
+                s, e = v * real + i * mb, min((v + 1) * real, v * real + (i + 1) * mb)
+                self.fprop([np.ascontiguousarray(d[:, s:e]) for d in data], PASS_TEST)
+                acts = logreg.prev[1].acts
+                sm = acts.copy() if v == 0 else (sm + acts).astype(np.float32)
+            sm = (sm * np.float32(1.0 / num_views)).astype(np.float32)
+            logreg.fprop([logreg.prev[0].acts, sm], PASS_TEST)
+            for k, vals in self.get_cost().items():
+                acc = tot.setdefault(k, [0.0] * len(vals))
+                for j, x in enumerate(vals):
+                    acc[j] += x
+            cases += self.num_cases
+        return tot, cases
+
     def sync_with_host(self):
         for l in self.layers:
             l.copy_to_host()

@@ -71,6 +71,44 @@ def test_extension_exposes_the_reference_methods():
         _ConvNet.startBatch([], 0)
 
 
+def test_weight_sharing_is_refused_at_init_model():
+    """`weightSource` (weights.cuh:59-68) parses like in the reference but has no parity coverage: initModel must fail
+    loudly rather than train on unverified gradients (the graph is built before any device call, so this runs on CPU)."""
+    from cuda_convnet_amd import _ConvNet
+    from cuda_convnet_amd.data import SyntheticDataProvider
+    here = os.path.dirname(os.path.abspath(__file__))
+    dp = SyntheticDataProvider('dummy', 32, img=(4, 4, 3), minibatch=32, num_classes=10)
+    dims = {i: dp.get_data_dims(i) for i in range(len(dp.dims))}
+    L = layer.parse_layers(os.path.join(here, 'cfg', 'shared.cfg'), os.path.join(here, 'cfg', 'shared_params.cfg'), dims, 10, seed=1)
+    fc2 = L[layer.layer_index(L, 'fc2')]
+    assert fc2['weightSourceLayerIndices'] == [layer.layer_index(L, 'fc1')] and fc2['weightSourceMatrixIndices'] == [0]
+    with pytest.raises(RuntimeError, match='weight sharing'):
+        _ConvNet.initModel(L, 32, 0)
+    with pytest.raises(RuntimeError):
+        _ConvNet.finishBatch()  # no model was left behind
+
+
+def test_checkpoint_loader_admits_arrays_and_nothing_else(tmp_path):
+    import pickle
+    from cuda_convnet_amd.convnet import ConvNet
+    good = {'model_state': {'layers': [{'name': 'fc', 'weights': [np.asfortranarray(np.arange(6, dtype=np.float32).reshape(3, 2))],
+                                        'epsW': [0.1], 'neuron': {'type': 'relu', 'params': {}}}], 'epoch': 2, 'batchnum': 7}, 'op': {'seed': 3}}
+    p = tmp_path / 'ok'
+    p.write_bytes(pickle.dumps(good, protocol=pickle.HIGHEST_PROTOCOL))
+    back = ConvNet.load_state(str(p))
+    w = back['model_state']['layers'][0]['weights'][0]
+    assert w.flags['F_CONTIGUOUS'] and np.array_equal(w, good['model_state']['layers'][0]['weights'][0]) and back['op'] == {'seed': 3}
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+
+    q = tmp_path / 'bad'
+    q.write_bytes(pickle.dumps({'model_state': Evil()}))
+    with pytest.raises(pickle.UnpicklingError):
+        ConvNet.load_state(str(q))
+
+
 # ------------------------------------------------------------------------------------ cfg parser
 def test_deepid2_dicts_follow_the_reference_schema():
     L = parse('deepid2')

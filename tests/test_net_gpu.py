@@ -104,7 +104,57 @@ def test_train_3_steps_matches_oracle(name):
     check_weights(Lg, Lc)
 
 
-@pytest.mark.parametrize('name', ['deepid2', 'cifar10'])
+def expected_buckets(segments, bucket_floats):
+    """The plan of DESIGN.md section 6: segments in arena order (= reverse layer order = completion order of backward) are
+    merged until a bucket holds at least bucket_floats; what is left when backward ends goes in one last exchange.  The
+    last weight layer of a pass is finished by the main thread and always travels with that last exchange."""
+    out, start = [], 0
+    for i, (name, b, e) in enumerate(segments):
+        last = i == len(segments) - 1
+        if not last and e - start >= bucket_floats:
+            out.append((start, e - start))
+            start = e
+    total = segments[-1][2]
+    if total > start:
+        out.append((start, total - start))
+    return out
+
+
+@pytest.mark.parametrize('name', ['deepid2', 'deepid2plus', 'deepid-attr'])
+def test_data_parallel_plan_is_the_documented_one_and_repeats(name):
+    """Every rank must issue the same collectives in the same order or RCCL hangs.  With a one-rank communicator the
+    exchange thread still runs the whole plan; its log must (1) cover the gradient arena exactly once per step with
+    buckets that end on layer boundaries, (2) be the greedy plan above, (3) put the L2-SN all-gather pair before the
+    all-reduces, (4) repeat identically every step and across two models."""
+    logs = []
+    for run in range(2):
+        dp, Lg = preset(name, 384)
+        data = dp.get_next_batch()[2]
+        with Native(Lg) as lib:
+            lib.initDataParallel(0, 1, lib.commUniqueId(), 1)
+            segments, bucket = lib.getGradSegments()
+            lib.getCommLog()
+            lib.startBatch(data, 0)
+            lib.finishBatch()
+            logs.append(lib.getCommLog())
+    assert logs[0] == logs[1], 'the exchange sequence differs between two identical runs'
+    log = logs[0]
+    assert len(log) % 3 == 0
+    per = len(log) // 3
+    steps = [log[i * per:(i + 1) * per] for i in range(3)]
+    assert steps[0] == steps[1] == steps[2], 'the exchange sequence differs from step to step'
+    gathers = [r for r in steps[0] if r[0] == 'allgather']
+    reduces = [(o, c) for k, o, c in steps[0] if k == 'allreduce']
+    assert len(gathers) == 2 and all(c == 64 for _, _, c in gathers) and steps[0][:2] == gathers  # pair distances, pair labels first
+    assert reduces == expected_buckets(segments, bucket), (reduces, segments, bucket)
+    ends = {e for _, _, e in segments}
+    assert all(o + c in ends for o, c in reduces)
+    if name == 'deepid2':  # DESIGN.md section 6: fc6 | fc5 + local4 + local3 | conv2 + conv1
+        names = [[n for n, b, e in segments if o <= b and e <= o + c] for o, c in reduces]
+        assert names == [['fc6'], ['fc5', 'local4', 'local3'], ['conv2', 'conv1']], names
+
+
+@pytest.mark.parametrize('name', ['deepid2', 'cifar10', 'deepid2plus'])
 def test_data_parallel_path_single_rank(name):
     """The replica-exchange path (raw gradients into the arena, bucketed RCCL all-reduce on the side stream,
     momentum folded after the exchange, L2-SN margin over all-gathered pairs) with a one-rank communicator
@@ -174,6 +224,90 @@ def test_write_features_matches_oracle():
             want = onet.write_features(data, idx)
             err = np.max(np.abs(ftrs - want))
             assert err <= 1e-4 * np.max(np.abs(want)) + 1e-6, (lname, err)
+
+
+@pytest.mark.parametrize('name,real,views', [('cifar10', 200, 3), ('deepid-39x31', 128, 2), ('deepid2', 96, 2)])
+def test_multiview_test_matches_oracle(name, real, views):
+    """startMultiviewTest (pyconvnet.cu:112-127, MultiviewTestWorker worker.cu:142-174): probabilities averaged over the
+    views of each case, logreg cost of the average; the other costs report their last view."""
+    dp, Lg = preset(name, real * views)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    # the views of a case share its label (view-major layout: case c of view v is column v*real + c)
+    data[1] = np.ascontiguousarray(np.tile(data[1][:, :real], (1, views)))
+    idx = layer.layer_index(Lg, 'logprob')
+    want = OracleNet(Lc, 128).run_multiview(data, views, idx)
+    with Native(Lg) as lib:
+        lib.startMultiviewTest(data, views, idx)
+        got = lib.finishBatch()
+    assert got[1] == want[1] == real
+    check_costs(got, want)
+
+
+def test_checkpoint_save_load_resume_is_bit_identical(tmp_path):
+    """gpumodel.py:254-281 / convnet.py:55-60: syncWithHost fills the weight AND momentum arrays, save_state pickles
+    {'model_state', 'op'}, a new process-model built from the checkpoint's layers (hyper-parameters refreshed from the
+    params file) continues exactly where the first stopped: the step after resume equals the uninterrupted run's."""
+    from cuda_convnet_amd.convnet import ConvNet, make_preset
+    ldef, lpar, kind, img = PRESETS['deepid-attr']
+    kw = dict(num_cases=256, num_batches=3)
+
+    def weights(net):
+        return [np.array(a) for l in net.layers if 'weights' in l for a in l['weights'] + l['weightsInc'] + [l['biases'], l['biasesInc']]]
+
+    straight = make_preset('deepid-attr', **kw)
+    try:
+        straight.train(1, quiet=True)  # one epoch = three data batches of two minibatches
+        straight.sync_with_host()
+        want = weights(straight)
+    finally:
+        straight.close()
+
+    first = make_preset('deepid-attr', **kw)
+    try:
+        dp = first.train_data_provider
+        for _ in range(2):
+            first.start_batch(dp.get_next_batch())
+            first.finish_batch()
+        first.epoch, first.batchnum = 1, 2
+        first.sync_with_host()
+        ck = str(tmp_path / 'ConvNet__test' / '1.2')
+        first.save_state(ck)
+    finally:
+        first.close()
+
+    st = ConvNet.load_state(ck)
+    assert set(st) == {'model_state', 'op'} and st['model_state']['batchnum'] == 2
+    dp2 = SyntheticDataProvider(kind, 256, num_batches=3, minibatch=128, img=img)
+    dp2.curr_batchnum = 3  # resume after batch 2
+    resumed = ConvNet(st['op']['layer_def'], st['op']['layer_params'], dp2, minibatch_size=st['op']['minibatch_size'],
+                      layers=st['model_state']['layers'])
+    try:
+        resumed.start_batch(dp2.get_next_batch())
+        resumed.finish_batch()
+        resumed.sync_with_host()
+        got = weights(resumed)
+    finally:
+        resumed.close()
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b), 'resumed training differs from the uninterrupted run'
+
+
+def test_write_features_mat_files(tmp_path):
+    """shownet.py:238-259: `data_batch_<n>.mat` with key 'feats', one per test batch."""
+    import scipy.io
+    from cuda_convnet_amd.convnet import make_preset
+    net = make_preset('deepid-39x31', num_cases=200, num_batches=2)
+    try:
+        paths = net.write_features_mat('fc5', str(tmp_path / 'ftrs'))
+        assert [os.path.basename(p) for p in paths] == ['data_batch_1.mat', 'data_batch_2.mat']
+        data = net.test_data_provider.make_batch(2)
+        want = net.write_features('fc5', data)
+        got = scipy.io.loadmat(paths[1])['feats']
+        assert got.dtype == np.float32 and np.array_equal(got, want) and got.shape == (200, 160)
+    finally:
+        net.close()
 
 
 def small_net(cases, scale=1.0):
