@@ -144,6 +144,10 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--force-dp', action='store_true', help='run the replica-exchange path even with one rank (rehearsal)')
     ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--host-data', action='store_true',
+                    help='also time the loop with every data batch coming from host memory (prefetchBatch: uploaded over the copy '
+                         'stream while the previous batch trains) and report it as upload_inclusive next to the resident value')
+    ap.add_argument('--pageable', action='store_true', help='--host-data: plain numpy arrays instead of page-locked ones')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -202,6 +206,33 @@ def main():
     for k, v in costs.items():
         assert all(np.isfinite(v)), ('non-finite cost', k, v)
 
+    inclusive = None
+    if a.host_data and world == 1:
+        # distinct host batches, cycled; batch k+1 is uploaded while batch k trains (the reference uploads on the compute
+        # thread: data.cu:72-98); the timed region starts with batch 0 still on the host
+        nb = max(3, -(-a.steps // a.resident_minibatches))
+        host = []
+        for b in range(3):
+            d = SyntheticDataProvider(kind, cases, img=img, minibatch=mb, seed=50 + b).get_next_batch()[2]
+            if not a.pageable:
+                pin = [lib.pinnedArray(*x.shape) for x in d]
+                for p_, x in zip(pin, d):
+                    p_[...] = x
+                d = pin
+            host.append(d)
+        lib.startBatch(host[0], 0)
+        lib.finishBatch()
+        t0 = time.perf_counter()
+        lib.startBatch(host[0], 0)
+        for k in range(1, nb):
+            lib.prefetchBatch(host[k % 3])
+            lib.finishBatch()
+            lib.startBatch([], 0)
+        lib.finishBatch()
+        dti = time.perf_counter() - t0
+        inclusive = {'value': round(nb * cases / dti, 1), 'unit': 'images/sec', 'batches': nb, 'cases_per_batch': cases,
+                     'host_memory': 'pageable' if a.pageable else 'page-locked', 'bytes_per_image': int(sum(x.shape[0] for x in host[0]) * 4)}
+
     prof = {}
     if not a.no_profile:
         lib.startSteps(a.profile_steps, 0, 1)
@@ -241,6 +272,9 @@ def main():
             out['filter_acts_frac_of_fp32_mfma_peak'] = {e['op']: e['frac'] for e in ks
                                                          if e['op'].split('.')[0] in conv_names and '.fprop[' in e['op']}
             out['kernels'] = ks
+        if inclusive:
+            inclusive['fraction_of_resident'] = round(inclusive['value'] / out['value'], 3)
+            out['upload_inclusive'] = inclusive
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.workload)
         sys.stdout.flush()

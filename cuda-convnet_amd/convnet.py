@@ -128,14 +128,24 @@ class ConvNet:
         r = self.train_data_provider.batch_range
         return len(r) * (self.epoch - 1) + self.batchnum - r[0] + 1
 
-    def train(self, num_epochs, quiet=False):
+    def train(self, num_epochs, quiet=False, prefetch=True):
+        """gpumodel.py:128-163, plus: the batch fetched while the current one computes is also UPLOADED meanwhile
+        (prefetchBatch: copy stream, own thread), so the next start_batch finds it in HBM."""
         next_data = self.train_data_provider.get_next_batch()
+        uploaded = False
         while next_data[0] <= num_epochs:
             data = next_data
             self.epoch, self.batchnum = data[0], data[1]
             t0 = time.time()
-            self.start_batch(data)
+            if uploaded:
+                self.libmodel.startBatch([], 0)
+            else:
+                self.start_batch(data)
             next_data = self.train_data_provider.get_next_batch()  # load the next batch while this one computes
+            uploaded = prefetch and next_data[0] <= num_epochs
+            if uploaded:
+                self._keep_next = self.shard(next_data[2])
+                self.libmodel.prefetchBatch(self._keep_next)
             out = self.finish_batch()
             self.train_outputs.append(out)
             if not quiet and self.rank == 0:

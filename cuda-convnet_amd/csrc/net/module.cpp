@@ -1,6 +1,7 @@
 // CPython 3 extension module `_ConvNet`: the drop-in boundary of the reference
 // (src/pyconvnet.cu:47-204, seven methods with the same names, argument meaning and
 // return values) plus six additions the reference has no need for:
+//   prefetchBatch(data) / pinnedArray    asynchronous upload of the next batch (copy stream, own thread) / page-locked arrays
 //   loadBatch(data)                      upload a data batch and keep it resident in HBM (blocking);
 //                                        a following startBatch([], test) trains/tests on it
 //   commUniqueId() -> bytes              RCCL unique id (rank 0 creates, the launcher distributes it)
@@ -29,6 +30,23 @@ static ConvNet* model = nullptr;         // pyconvnet.cu:45: one model per proce
 static PyObject* modelLayers = nullptr;  // keeps the weight arrays alive (they are written in place by syncWithHost)
 static std::deque<std::vector<PyObject*>> inflight;  // arrays lent to queued work items
 
+// page-locked allocations handed out by pinnedArray: [begin, end) address ranges
+static std::map<uintptr_t, uintptr_t> pinnedRanges;
+static bool isPinned(const void* p, size_t bytes) {
+    const uintptr_t a = (uintptr_t)p;
+    auto it = pinnedRanges.upper_bound(a);
+    if (it == pinnedRanges.begin()) return false;
+    --it;
+    return a >= it->first && a + bytes <= it->second;
+}
+static void pinnedCapsuleFree(PyObject* cap) {
+    void* p = PyCapsule_GetPointer(cap, "mcn_pinned");
+    if (p) {
+        pinnedRanges.erase((uintptr_t)p);
+        mcn_host_free(p);
+    }
+}
+
 static bool toHostMat(PyObject* o, HostMat& m) {
     if (!PyArray_Check(o)) return false;
     PyArrayObject* a = (PyArrayObject*)o;
@@ -39,6 +57,7 @@ static bool toHostMat(PyObject* o, HostMat& m) {
     m.rows = (long)PyArray_DIM(a, 0);
     m.cols = (long)PyArray_DIM(a, 1);
     m.fortran = !c;  // matrix.cpp:71-90: C-contiguous -> not transposed, F-contiguous -> transposed view
+    m.pinned = isPinned(m.data, m.size() * sizeof(float));
     return true;
 }
 
@@ -152,13 +171,16 @@ static PyObject* initModel(PyObject*, PyObject* args) {  // pyconvnet.cu:69-88
     return Py_BuildValue("i", 0);
 }
 
+static std::vector<PyObject*> prefetchRefs;
 static PyObject* destroyModel(PyObject*, PyObject*) {
     if (model) {
         Py_BEGIN_ALLOW_THREADS
+        try { model->waitPrefetchUploaded(); } catch (...) {}
         delete model;
         Py_END_ALLOW_THREADS
         model = nullptr;
     }
+    releaseRefs(prefetchRefs);
     for (auto& v : inflight) releaseRefs(v);
     inflight.clear();
     Py_CLEAR(modelLayers);
@@ -175,6 +197,7 @@ static PyObject* startBatch(PyObject*, PyObject* args) {  // pyconvnet.cu:93-107
     const bool resident = PyList_GET_SIZE(data) == 0;
     if (!toCPUData(data, cd, refs, PyList_GET_SIZE(data))) { releaseRefs(refs); return nullptr; }
     inflight.push_back(refs);
+    if (resident) model->dp().claimPrefetch();
     model->workQueue().enqueue([cd, test, resident](ConvNet& n) { n.runTraining(cd, test != 0, resident); });
     return Py_BuildValue("i", 0);
 }
@@ -190,6 +213,56 @@ static PyObject* loadBatch(PyObject*, PyObject* args) {
     model->workQueue().enqueue([cd](ConvNet& n) { n.runLoad(cd); });
     WorkResult r;
     if (!waitResult(r)) return nullptr;
+    return Py_BuildValue("i", 0);
+}
+
+// pinnedArray(rows, cols) -> C-contiguous float32 array in page-locked host memory (freed with the array).  Data providers
+// that fill such arrays skip the staging copy: the batch goes to the device by DMA straight from them.
+static PyObject* pinnedArray(PyObject*, PyObject* args) {
+    long rows, cols;
+    if (!PyArg_ParseTuple(args, "ll", &rows, &cols)) return nullptr;
+    if (rows <= 0 || cols <= 0) { PyErr_SetString(PyExc_ValueError, "pinnedArray: positive dimensions expected"); return nullptr; }
+    void* p = nullptr;
+    const size_t bytes = (size_t)rows * cols * sizeof(float);
+    if (mcn_host_alloc(&p, bytes) != MCN_OK) { PyErr_SetString(PyExc_RuntimeError, mcn_last_error()); return nullptr; }
+    npy_intp dims[2] = {rows, cols};
+    PyObject* arr = PyArray_SimpleNewFromData(2, dims, NPY_FLOAT32, p);
+    PyObject* cap = PyCapsule_New(p, "mcn_pinned", pinnedCapsuleFree);
+    if (!arr || !cap || PyArray_SetBaseObject((PyArrayObject*)arr, cap) != 0) {
+        Py_XDECREF(arr);
+        mcn_host_free(p);
+        return nullptr;
+    }
+    pinnedRanges[(uintptr_t)p] = (uintptr_t)p + bytes;
+    return arr;
+}
+
+// prefetchBatch(data): asynchronous upload of the NEXT batch into the spare device slot (own thread, own stream) while the
+// current one trains; the following startBatch([], test) trains / tests on it.  The arrays are kept alive until the transfer
+// has completed (checked at the next prefetchBatch / destroyModel).
+static PyObject* prefetchBatch(PyObject*, PyObject* args) {
+    PyObject* data;
+    if (!PyArg_ParseTuple(args, "O!", &PyList_Type, &data)) return nullptr;
+    if (!needModel()) return nullptr;
+    CPUData cd;
+    std::vector<PyObject*> refs;
+    if (!toCPUData(data, cd, refs, PyList_GET_SIZE(data))) { releaseRefs(refs); return nullptr; }
+    std::string err;
+    Py_BEGIN_ALLOW_THREADS
+    try {
+        model->waitPrefetchUploaded();  // the previous prefetch no longer reads its host arrays
+        model->prefetchFromHost(cd);
+    } catch (std::exception& e) {
+        err = e.what();
+    }
+    Py_END_ALLOW_THREADS
+    releaseRefs(prefetchRefs);
+    if (!err.empty()) {
+        releaseRefs(refs);
+        PyErr_SetString(PyExc_RuntimeError, ("_ConvNet: " + err).c_str());
+        return nullptr;
+    }
+    prefetchRefs = refs;
     return Py_BuildValue("i", 0);
 }
 
@@ -365,6 +438,8 @@ static PyMethodDef methods[] = {
     {"startFeatureWriter", startFeatureWriter, METH_VARARGS, "startFeatureWriter(data + [ftrs], layerIdx)"},
     {"syncWithHost", syncWithHost, METH_VARARGS, "syncWithHost(): fills the weight arrays of `layers` in place"},
     {"loadBatch", loadBatch, METH_VARARGS, "loadBatch(data): upload and keep resident (blocking)"},
+    {"prefetchBatch", prefetchBatch, METH_VARARGS, "prefetchBatch(data): upload the NEXT batch on the copy stream while the current one trains; startBatch([], test) then uses it"},
+    {"pinnedArray", pinnedArray, METH_VARARGS, "pinnedArray(rows, cols) -> float32 C array in page-locked host memory"},
     {"startSteps", startSteps, METH_VARARGS, "startSteps(numSteps, test=0, profile=0): minibatch steps cycling over the resident batch (asynchronous)"},
     {"getProfile", getProfile, METH_NOARGS, "getProfile() -> {operation: (count, total device ms)} of the last profiled startSteps"},
     {"commUniqueId", commUniqueId, METH_NOARGS, "commUniqueId() -> 128 bytes"},

@@ -775,8 +775,9 @@ void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
     if (i != 0) return;
     // the cost value is off the critical path (nothing downstream reads it): side stream
     float *labels = _inputs[0], *probs = _inputs[1];
-    _net->deferLateWork([this, labels, probs] {
-        chk(mcn_logreg_cost(labels, probs, _acts, _aux.p, _prev[1]->outputs(), _net->numCases(), dCost, _net->workspace(),
+    const int n = _net->numCases();  // (captured now: in a test pass the closure runs while the NEXT minibatch is being set up)
+    _net->deferLateWork([this, labels, probs, n] {
+        chk(mcn_logreg_cost(labels, probs, _acts, _aux.p, _prev[1]->outputs(), n, dCost, _net->workspace(),
                             _net->workspaceBytes(), _net->stream()), "logreg cost");
     });
 }
@@ -893,8 +894,9 @@ void Fisher2CostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1025-103
     if (i != 0) return;
     if (_net->dataParallel()) throw NetError("cost.fisher2 couples every pair of the minibatch: not defined for data-parallel replicas");
     float *labels = _inputs[0], *data = _inputs[1];
-    _net->deferSideWork([this, labels, data] {  // the value is read by nothing downstream
-        chk(mcn_fisher2_cost(labels, data, _prev[1]->outputs(), _net->numCases(), _alpha, dCost, _net->workspace(), _net->workspaceBytes(),
+    const int n = _net->numCases();
+    _net->deferSideWork([this, labels, data, n] {  // the value is read by nothing downstream
+        chk(mcn_fisher2_cost(labels, data, _prev[1]->outputs(), n, _alpha, dCost, _net->workspace(), _net->workspaceBytes(),
                              _net->stream()), "fisher2 cost");
     }, 0);
 }
@@ -908,8 +910,9 @@ void Fisher2CostLayer::bpropActs(float*, int i, float scaleTargets, PassType) { 
 void L2regCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:1093-1105
     if (i != 0) return;
     float *ground = _inputs[0], *pred = _inputs[1];
-    _net->deferSideWork([this, ground, pred] {
-        chk(mcn_l2reg_cost(ground, pred, _acts, _prev[1]->outputs(), _net->numCases(), dCost, _net->stream()), "l2reg cost");
+    const int n = _net->numCases();
+    _net->deferSideWork([this, ground, pred, n] {
+        chk(mcn_l2reg_cost(ground, pred, _acts, _prev[1]->outputs(), n, dCost, _net->stream()), "l2reg cost");
     }, 0);
 }
 
@@ -919,7 +922,194 @@ void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  /
                        scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2reg grad");
 }
 
+// ============================================================================ Uploader
+static thread_local int t_stream = 0;  // which stream this submitting thread feeds: 0 main, 1 side, 2 exchange, 3 copy
+
+void Uploader::start(int deviceID) {
+    chk(mcn_stream_create(&_stream), "copy stream");
+    for (int k = 0; k < 2; k++) {
+        chk(mcn_host_alloc(&_chunk[k], kChunkBytes), "pinned staging chunk");
+        chk(mcn_event_create_sync(&_chunkEv[k]), "event");
+    }
+    _thread.start(deviceID);
+}
+
+void Uploader::stop() { _thread.stop(); }
+
+Uploader::~Uploader() {
+    stop();
+    for (int k = 0; k < 2; k++) {
+        if (_chunkEv[k]) mcn_event_destroy(_chunkEv[k]);
+        if (_chunk[k]) mcn_host_free(_chunk[k]);
+    }
+    if (_stream) mcn_stream_destroy(_stream);
+}
+
+void* Uploader::acquireChunk(int& k) {
+    k = _next++ & 1;
+    if (_chunkUsed[k]) chk(mcn_event_sync(_chunkEv[k]), "event sync");  // the DMA out of this chunk has finished
+    _chunkUsed[k] = true;
+    return _chunk[k];
+}
+
+void Uploader::copy(float* dst, const float* src, size_t bytes, bool pinned) {
+    if (pinned) {
+        chk(mcn_h2d(dst, src, bytes, _stream), "h2d (pinned)");
+        return;
+    }
+    for (size_t off = 0; off < bytes; off += kChunkBytes) {
+        const size_t n = std::min(kChunkBytes, bytes - off);
+        int k;
+        void* c = acquireChunk(k);
+        memcpy(c, (const char*)src + off, n);
+        chk(mcn_h2d((char*)dst + off, c, n, _stream), "h2d (staged)");
+        chk(mcn_event_record(_chunkEv[k], _stream), "event record");
+    }
+}
+
+void Uploader::copy2d(float* dst, size_t dpitch, const float* src, size_t spitch, size_t width, size_t height, bool pinned) {
+    if (pinned) {
+        chk(mcn_copy2d(dst, dpitch, src, spitch, width, height, 0, _stream), "h2d 2d (pinned)");
+        return;
+    }
+    // gather the strided rows into a staging chunk, then one dense copy per chunk
+    const size_t rowsPerChunk = std::max<size_t>(1, kChunkBytes / width);
+    for (size_t r0 = 0; r0 < height; r0 += rowsPerChunk) {
+        const size_t rows = std::min(rowsPerChunk, height - r0);
+        int k;
+        char* c = (char*)acquireChunk(k);
+        for (size_t r = 0; r < rows; r++) memcpy(c + r * width, (const char*)src + (r0 + r) * spitch, width);
+        if (dpitch == width) chk(mcn_h2d((char*)dst + r0 * dpitch, c, rows * width, _stream), "h2d (staged)");
+        else chk(mcn_copy2d((char*)dst + r0 * dpitch, dpitch, c, width, width, rows, 0, _stream), "h2d 2d (staged)");
+        chk(mcn_event_record(_chunkEv[k], _stream), "event record");
+    }
+}
+
 // ============================================================================ DataProvider (data.cu)
+DataProvider::~DataProvider() {
+    for (void* e : {_evNext, _evSlotFree, _evSliceReady[0], _evSliceReady[1], _evSliceFree[0], _evSliceFree[1]})
+        if (e) mcn_event_destroy(e);
+}
+
+// Spare-slot upload on the uploader thread / copy stream; the caller keeps the host arrays alive until waitPrefetchUploaded.
+void DataProvider::prefetch(const CPUData& d) {
+    Uploader& up = _net->uploader();
+    if (!up.running()) throw NetError("prefetchBatch: the upload thread is not running");
+    if (d.numCases() <= 0) throw NetError("data batch has no cases");
+    for (const HostMat& m : d.mats)
+        if (m.cols != d.numCases()) throw NetError("data matrices differ in the number of cases");
+    // the spare slot may hold a batch whose adoption (startBatch([])) is queued but has not run yet: wait for the swap
+    while (_adoptQueued.load()) std::this_thread::yield();
+    if (_nextTicket.load()) up.wait(_nextTicket.load());  // a prefetch nobody asked to adopt is simply replaced
+    _nextTicket = up.push([this, d] {
+        Uploader& u = _net->uploader();
+        if (!_evNext) chk(mcn_event_create_sync(&_evNext), "event");
+        while (_devNext.size() < d.mats.size()) {
+            _devNext.emplace_back(new DBuf());
+            _tiledNext.emplace_back(new DBuf());
+        }
+        _dimsNext.clear();
+        _numCasesNext = d.numCases();
+        for (size_t i = 0; i < d.mats.size(); i++) {
+            const HostMat& m = d.mats[i];
+            _dimsNext.push_back(m.rows);
+            _devNext[i]->ensure(m.size());
+            _tiledNext[i]->ensure(m.size());
+            u.copy(_devNext[i]->p, m.data, m.size() * 4, m.pinned);
+            chk(mcn_tile_minibatches(_devNext[i]->p, _tiledNext[i]->p, (int)m.rows, (size_t)_numCasesNext, _minibatchSize, u.stream()),
+                "tile minibatches");
+        }
+        chk(mcn_event_record(_evNext, u.stream()), "event record");
+    });
+}
+
+void DataProvider::waitPrefetchUploaded() {
+    const long t = _nextTicket.load();
+    if (!t) return;
+    _net->uploader().wait(t);
+    if (_evNext) chk(mcn_event_sync(_evNext), "event sync");
+}
+
+// compute thread: the prefetched batch becomes the current one (the old current slot becomes the spare)
+void DataProvider::adoptPrefetched() {
+    if (!_nextTicket.load()) { _adoptQueued.store(false); throw NetError("no prefetched data batch"); }
+    _net->uploader().wait(_nextTicket.load());  // its copies and the event record have been issued
+    chk(mcn_stream_wait_event(_net->mainStream(), _evNext), "wait event");
+    while (_dev.size() < _devNext.size()) {
+        _dev.emplace_back(new DBuf());
+        _mini.emplace_back(new DBuf());
+        _tiled.emplace_back(new DBuf());
+    }
+    while (_devNext.size() < _dev.size()) {
+        _devNext.emplace_back(new DBuf());
+        _tiledNext.emplace_back(new DBuf());
+    }
+    std::swap(_dev, _devNext);
+    std::swap(_tiled, _tiledNext);
+    _dims = _dimsNext;
+    _numCases = _numCasesNext;
+    _onDevice = true;
+    _host = CPUData();
+    _nextTicket.store(0);
+    _adoptQueued.store(false);  // the spare slot (the batch trained before) may be overwritten from here on
+}
+
+void DataProvider::markBatchIssued() {}
+
+// ---- streamed minibatches: the batch stays on the host (reference: batches above 200 MB, util.cuh:53 / data.cu:72-98);
+// slice i+2 is copied on the copy stream while steps i and i+1 run.
+void DataProvider::requestSlice(int mi) {
+    const int b = mi & 1;
+    Uploader& up = _net->uploader();
+    const long start = (long)mi * _minibatchSize, end = std::min(start + _minibatchSize, _numCases);
+    if (start >= _numCases) { _sliceTicket[b] = 0; return; }
+    const CPUData host = _host;
+    void* evFree = _sliceFreeRecorded[b] ? _evSliceFree[b] : nullptr;
+    _sliceTicket[b] = up.push([this, host, b, start, end, evFree] {
+        Uploader& u = _net->uploader();
+        if (evFree) chk(mcn_stream_wait_event(u.stream(), evFree), "wait event");  // the step that read this buffer is done
+        const long n = end - start;
+        for (size_t i = 0; i < host.mats.size(); i++) {
+            float* dst = _stream2[b][i]->p;
+            u.copy2d(dst, (size_t)n * 4, host.mats[i].data + start, (size_t)_numCases * 4, (size_t)n * 4, (size_t)_dims[i], host.mats[i].pinned);
+        }
+        chk(mcn_event_record(_evSliceReady[b], u.stream()), "event record");
+    });
+}
+
+void DataProvider::streamBegin() {
+    if (!_net->uploader().running()) throw NetError("streamed minibatches need the upload thread");
+    for (int b = 0; b < 2; b++) {
+        if (!_evSliceReady[b]) chk(mcn_event_create_sync(&_evSliceReady[b]), "event");
+        if (!_evSliceFree[b]) chk(mcn_event_create_sync(&_evSliceFree[b]), "event");
+        while (_stream2[b].size() < _dims.size()) _stream2[b].emplace_back(new DBuf());
+        for (size_t i = 0; i < _dims.size(); i++) _stream2[b][i]->ensure((size_t)_dims[i] * _minibatchSize);
+    }
+    // the compute stream may still read the buffers (previous batch): order the first refills behind it
+    for (int b = 0; b < 2; b++) {
+        chk(mcn_event_record(_evSliceFree[b], _net->mainStream()), "event record");
+        _sliceFreeRecorded[b] = true;
+    }
+    requestSlice(0);
+    requestSlice(1);
+}
+
+void DataProvider::streamSlice(int mi, std::vector<float*>& out) {
+    const int b = mi & 1;
+    if (!_sliceTicket[b]) throw NetError("streamed minibatch was not requested");
+    _net->uploader().wait(_sliceTicket[b]);
+    chk(mcn_stream_wait_event(_net->mainStream(), _evSliceReady[b]), "wait event");
+    out.clear();
+    for (size_t i = 0; i < _dims.size(); i++) out.push_back(_stream2[b][i]->p);
+}
+
+void DataProvider::streamSliceDone(int mi) {
+    const int b = mi & 1;
+    chk(mcn_event_record(_evSliceFree[b], _net->mainStream()), "event record");
+    _sliceFreeRecorded[b] = true;
+    requestSlice(mi + 2);
+}
+
 void DataProvider::setData(const CPUData& d) {
     _host = d;
     _numCases = d.numCases();
@@ -944,6 +1134,7 @@ void DataProvider::setData(const CPUData& d) {
     if (_onDevice) {
         for (size_t i = 0; i < d.mats.size(); i++) {
             _dev[i]->ensure(d.mats[i].size());
+            // (page-locked sources go out asynchronously; pageable ones are staged by the runtime inside this call)
             chk(mcn_h2d(_dev[i]->p, d.mats[i].data, d.mats[i].size() * 4, _net->stream()), "h2d data batch");
             // every minibatch slice laid out densely once per batch: the per-step slice is then a pointer
             _tiled[i]->ensure(d.mats[i].size());
@@ -1038,8 +1229,11 @@ void ConvNet::dropStepGraphs() {
     _stepGraphs.clear();
 }
 
+void ConvNet::prefetchFromHost(const CPUData& d) { _dp->prefetch(d); }
+
 ConvNet::~ConvNet() {
     stop();
+    _uploader.stop();
     dropStepGraphs();
     _side.stop();
     _commSub.stop();
@@ -1166,6 +1360,7 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
         for (void*& e : _forkEvents) chk(mcn_event_create_sync(&e), "event");
         _side.start(_deviceID);
     }
+    _uploader.start(_deviceID);
     for (auto& l : _layers) l->copyToGPU();
     buildFusions();
     allocate(_minibatchSize);
@@ -1259,8 +1454,6 @@ void ConvNet::sync() {
 }
 
 // ---- side-stream submission -----------------------------------------------------------------
-static thread_local int t_stream = 0;  // which stream this submitting thread feeds: 0 main, 1 side, 2 exchange
-
 void* ConvNet::stream() const { return t_stream == 1 ? _gradStream : t_stream == 2 ? _commStream : _stream; }
 void* ConvNet::workspace() const { return t_stream == 1 ? _ws2.p : _ws.p; }  // (exchange-thread work uses no workspace)
 

@@ -397,6 +397,20 @@ struct CPUData {
 class DataProvider {
    public:
     explicit DataProvider(ConvNet* net, int minibatchSize) : _net(net), _minibatchSize(minibatchSize) {}
+    ~DataProvider();
+    // upload `d` into the spare slot on the copy stream while the current batch trains; adopt() swaps it in
+    void prefetch(const CPUData& d);
+    bool prefetchPending() const { return _nextTicket.load() != 0; }
+    // caller's thread, when it queues the work item that will adopt the pending prefetch: a following prefetch() must not
+    // touch the spare slot before that adoption has happened
+    void claimPrefetch() { if (prefetchPending()) _adoptQueued.store(true); }
+    void adoptPrefetched();
+    void waitPrefetchUploaded();  // host-side: the transfer has completed (the caller may release the host arrays)
+    // batch too large to keep resident: minibatch slices uploaded two ahead of the step that reads them
+    bool streamed() const { return !_onDevice && !_host.mats.empty(); }
+    void streamBegin();
+    void streamSlice(int miniIdx, std::vector<float*>& out);   // waits for slice miniIdx, hands out its buffers
+    void streamSliceDone(int miniIdx);                          // the step reading it has been issued: refill the buffer
     void setData(const CPUData& d);            // data.cu:47-65 (uploads the whole batch when it fits)
     void clearHost() { _host = CPUData(); }
     void getSlice(long start, long end, std::vector<float*>& out);  // data.cu:72-98
@@ -413,6 +427,24 @@ class DataProvider {
     bool _onDevice = false;
     std::vector<long> _dims;
     std::vector<std::unique_ptr<DBuf>> _dev, _mini, _tiled;  // whole batch; one copied slice; all slices, minibatch-major
+    // spare slot (prefetch)
+    std::vector<std::unique_ptr<DBuf>> _devNext, _tiledNext;
+    std::vector<long> _dimsNext;
+    long _numCasesNext = 0;
+    std::atomic<long> _nextTicket{0};
+    std::atomic<bool> _adoptQueued{false};
+    void* _evNext = nullptr;      // recorded on the copy stream after the spare slot's upload + tiling
+    void* _evSlotFree = nullptr;  // recorded on the compute stream when the batch that used a slot has been fully issued
+    bool _slotFreeRecorded = false;
+    // streamed minibatches (double buffer)
+    std::vector<std::unique_ptr<DBuf>> _stream2[2];
+    void* _evSliceReady[2] = {nullptr, nullptr};
+    void* _evSliceFree[2] = {nullptr, nullptr};
+    long _sliceTicket[2] = {0, 0};
+    bool _sliceFreeRecorded[2] = {false, false};
+    void requestSlice(int miniIdx);
+   public:
+    void markBatchIssued();  // compute stream: everything reading the current slot has been enqueued
 };
 
 // ---- costs (cost.cu) ------------------------------------------------------------------------
@@ -498,6 +530,33 @@ class Submitter {
     bool* _flag = nullptr;
 };
 
+// Host -> device transfers on their own thread and stream (f1 of SURVEY 8f; the reference copies on the compute thread,
+// data.cu:72-98 / nvmatrix.cu:141-154, and overlaps only the Python-side file loading, gpumodel.py:148-151).  Pageable
+// sources go through two page-locked staging chunks (the CPU copy of chunk k+1 overlaps the DMA of chunk k); page-locked
+// sources (pinnedArray) are read by DMA directly.
+class Uploader {
+   public:
+    ~Uploader();
+    void start(int deviceID);
+    void stop();
+    bool running() const { return _thread.running(); }
+    void* stream() const { return _stream; }
+    long push(std::function<void()> fn) { return _thread.push(std::move(fn)); }
+    void wait(long ticket) { _thread.wait(ticket); }
+    // on the uploader thread only:
+    void copy(float* dst, const float* src, size_t bytes, bool pinned);
+    void copy2d(float* dst, size_t dpitchBytes, const float* src, size_t spitchBytes, size_t widthBytes, size_t height, bool pinned);
+   private:
+    Submitter _thread;
+    void* _stream = nullptr;
+    void* _chunk[2] = {nullptr, nullptr};
+    void* _chunkEv[2] = {nullptr, nullptr};
+    bool _chunkUsed[2] = {false, false};
+    int _next = 0;
+    static constexpr size_t kChunkBytes = (size_t)32 << 20;
+    void* acquireChunk(int& k);
+};
+
 class ConvNet {
    public:
     ConvNet(const std::vector<Params>& layers, int minibatchSize, int deviceID);
@@ -562,6 +621,9 @@ class ConvNet {
     Layer& layer(int i) { return *_layers[i]; }
     int numLayers() const { return (int)_layers.size(); }
     DataProvider& dp() { return *_dp; }
+    Uploader& uploader() { return _uploader; }
+    void prefetchFromHost(const CPUData& d);  // any thread: hands the batch to the uploader (asynchronous)
+    void waitPrefetchUploaded() { _dp->waitPrefetchUploaded(); }
     void gradReady(WeightLayer* l);             // data-parallel: layer's gradient segment is complete
     void allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // starts on the exchange stream
     void waitGather();
@@ -612,6 +674,7 @@ class ConvNet {
     // other down.  The main thread records the fork event and hands the closures over; the side thread waits for the
     // event on the side stream and issues them there.
     Submitter _side, _commSub;  // side stream and exchange stream
+    Uploader _uploader;
     std::vector<void*> _forkEvents;
     size_t _forkNext = 0;
     std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread

@@ -17,6 +17,7 @@ struct HostMat {
     float* data = nullptr;
     long rows = 0, cols = 0;
     bool fortran = false;
+    bool pinned = false;  // page-locked host memory (pinnedArray): DMA reads it directly, no staging copy
     size_t size() const { return (size_t)rows * cols; }
 };
 

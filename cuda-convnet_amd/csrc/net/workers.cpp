@@ -73,9 +73,34 @@ bool ConvNet::checkGradient(const std::string& name, float eps, Weights& w, std:
 // TrainingWorker::run (worker.cu:88-102).  useResident: run on the batch a previous runLoad left on the device.
 void ConvNet::runTraining(const CPUData& data, bool test, bool useResident) {
     if (!useResident) _dp->setData(data);
-    else if (!_dp->resident()) throw NetError("no resident data batch: call loadBatch first");
+    else if (_dp->prefetchPending()) _dp->adoptPrefetched();  // the batch prefetchBatch uploaded while the last one trained
+    else if (!_dp->resident()) throw NetError("no resident data batch: call loadBatch or prefetchBatch first");
     WorkResult res;
     zeroCosts();
+    if (_dp->streamed()) {
+        // batch kept on the host: slices arrive over the copy stream two steps ahead (the reference uploads each slice on the
+        // compute thread and waits for it, data.cu:72-98)
+        _dp->streamBegin();
+        for (int i = 0; i < _dp->numMinibatches(); i++) {
+            const long start = (long)i * _minibatchSize, end = std::min(start + _minibatchSize, _dp->numCases());
+            _numCases = (int)(end - start);
+            joinGradWork();
+            _dp->streamSlice(i, _curData);
+            fpropCurrent(test ? PASS_TEST : PASS_TRAIN);
+            if (!test) {
+                bprop(PASS_TRAIN);
+                updateWeights();
+                _stepsDone++;
+            }
+            joinGradWork();  // (cost kernels on the side stream read the labels of this slice)
+            _dp->streamSliceDone(i);
+        }
+        readCosts(res.cost, _dp->numCases());
+        _dp->clearHost();
+        res.type = WorkResult::BATCH_DONE;
+        _results.enqueue(std::move(res));
+        return;
+    }
     for (int i = 0; i < _dp->numMinibatches(); i++) {
         if (test) fprop(i, PASS_TEST);
         else trainStep(i);

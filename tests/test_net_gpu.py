@@ -189,6 +189,20 @@ def test_ragged_batches(name, cases):
     check_weights(Lg, Lc)
 
 
+@pytest.mark.parametrize('name', ['deepid2', 'deepid-attr', 'deepidn'])
+def test_test_pass_with_a_ragged_last_minibatch(name):
+    """Cost kernels are deferred past the forward pass that issued them; each must keep ITS minibatch's case count (a test
+    pass over 3 x 128 + 72 cases once counted the third minibatch with the fourth's 72 cases)."""
+    dp, Lg = preset(name, 456)
+    Lc = copy.deepcopy(Lg)
+    data = dp.get_next_batch()[2]
+    _, want = oracle_train(Lc, data, test=True)
+    with Native(Lg) as lib:
+        lib.startBatch(data, 1)
+        got = lib.finishBatch()
+    check_costs(got, want)
+
+
 def test_test_pass_leaves_weights_alone_and_resident_batch():
     dp, Lg = preset('deepid2', 256)
     Lc = copy.deepcopy(Lg)
@@ -308,6 +322,82 @@ def test_write_features_mat_files(tmp_path):
         assert got.dtype == np.float32 and np.array_equal(got, want) and got.shape == (200, 160)
     finally:
         net.close()
+
+
+def final_weights(L):
+    return [np.array(a) for l in L if 'weights' in l for a in l['weights'] + l['weightsInc'] + [l['biases'], l['biasesInc']]]
+
+
+@pytest.mark.parametrize('pinned', [False, True])
+def test_prefetched_batches_equal_plain_batches(pinned):
+    """f1: batch k+1 goes to the spare device slot over the copy stream (own thread; page-locked arrays by DMA, pageable ones
+    through two staging chunks) while batch k trains; startBatch([]) then trains on it.  Same weights, bit for bit, as
+    handing every batch to startBatch."""
+    dp, Lp = preset('deepid2', 256)
+    Lq = copy.deepcopy(Lp)
+    batches = []
+    for b in range(3):
+        dpb = SyntheticDataProvider('deepid2', 256, img=(55, 55, 3), minibatch=128, seed=11 + b)
+        batches.append(dpb.get_next_batch()[2])
+    with Native(Lp) as lib:
+        plain_costs = []
+        for data in batches:
+            lib.startBatch(data, 0)
+            plain_costs.append(lib.finishBatch())
+        lib.syncWithHost()
+    with Native(Lq) as lib:
+        if pinned:
+            staged = []
+            for data in batches:
+                arrs = [lib.pinnedArray(*d.shape) for d in data]
+                for a, d in zip(arrs, data):
+                    a[...] = d
+                staged.append(arrs)
+            batches = staged
+        costs = []
+        lib.startBatch(batches[0], 0)
+        for nxt in batches[1:]:
+            lib.prefetchBatch(nxt)
+            costs.append(lib.finishBatch())
+            lib.startBatch([], 0)
+        costs.append(lib.finishBatch())
+        lib.startBatch([], 1)  # the adopted batch stays resident: a test pass on it
+        lib.finishBatch()
+        lib.syncWithHost()
+    for a, b in zip(final_weights(Lq), final_weights(Lp)):
+        assert np.array_equal(a, b)
+    for (ga, na), (gb, nb_) in zip(costs, plain_costs):
+        assert na == nb_
+        for k in gb:
+            assert all(abs(x - y) <= 1e-9 * abs(y) for x, y in zip(ga[k], gb[k])), (k, ga[k], gb[k])
+
+
+@pytest.mark.parametrize('name,cases', [('deepid2', 456), ('deepid-attr', 256)])
+def test_batch_streamed_from_the_host_equals_resident_batch(name, cases, monkeypatch):
+    """MCN_MAX_DATA_ON_GPU_MB=0 (the reference's path for batches above 200 MB, util.cuh:53): the batch stays on the host and
+    minibatch slices arrive over the copy stream two steps ahead.  Same costs and weights as the resident batch."""
+    dp, La = preset(name, cases)
+    Lb = copy.deepcopy(La)
+    data = dp.get_next_batch()[2]
+    with Native(La) as lib:
+        lib.startBatch(data, 0)
+        ca = lib.finishBatch()
+        lib.startBatch(data, 1)
+        ta = lib.finishBatch()
+        lib.syncWithHost()
+    monkeypatch.setenv('MCN_MAX_DATA_ON_GPU_MB', '0')
+    with Native(Lb) as lib:
+        lib.startBatch(data, 0)
+        cb = lib.finishBatch()
+        lib.startBatch(data, 1)
+        tb = lib.finishBatch()
+        lib.syncWithHost()
+    for a, b in zip(final_weights(Lb), final_weights(La)):
+        assert np.array_equal(a, b)
+    for got, want in ((cb, ca), (tb, ta)):
+        assert got[1] == want[1]
+        for k in want[0]:
+            assert all(abs(x - y) <= 1e-9 * abs(y) + 1e-12 for x, y in zip(got[0][k], want[0][k])), (k, got[0][k], want[0][k])
 
 
 def small_net(cases, scale=1.0):
