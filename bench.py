@@ -104,8 +104,20 @@ def roofline_entry(layers, label, count, ms, N):
     return e
 
 
-def cpu_baseline(preset, budget_s=12.0):
-    """The whole-net CPU oracle on a bounded sample of the same workload (images/sec on host cores)."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(preset, budget_s=9.0, budget_one_s=6.0):
+    """The whole-net CPU oracle on a bounded sample of the same workload (images/sec on host cores): all cores the
+    process may use, then ONE core, with the CPU model."""
+    import ctypes
     import ccn_loader
     ccn_loader.load()
     from cuda_convnet_amd import CFG_DIR, layer
@@ -118,18 +130,33 @@ def cpu_baseline(preset, budget_s=12.0):
     L = layer.parse_layers(os.path.join(CFG_DIR, ldef), os.path.join(CFG_DIR, lpar), dims, dp.get_num_classes(), seed=3)
     net = OracleNet(L, 128)
     data = dp.get_next_batch()[2]
-    net.run_batch(data)  # warm-up (page in the library, first-touch the buffers)
-    t0 = time.time()
-    net.run_batch(data)
-    one = time.time() - t0
-    reps = int(max(1, min(512, budget_s / max(one, 1e-3))))  # ~12 s of CPU work
-    t0 = time.time()
-    for _ in range(reps):
-        net.run_batch(data)
-    dt = time.time() - t0
     cores = int(os.environ.get('OMP_NUM_THREADS', 0)) or len(os.sched_getaffinity(0))
-    return {'value': round(reps * 128 / dt, 1), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%d training minibatches of 128 (fprop+bprop+update), same net and synthetic data' % reps}
+    try:
+        gomp = ctypes.CDLL('libgomp.so.1')
+    except OSError:
+        gomp = None
+
+    def sample(threads, budget):
+        if gomp is not None:
+            gomp.omp_set_num_threads(threads)
+        net.run_batch(data)  # warm-up (page in the library, first-touch the buffers)
+        t0 = time.time()
+        net.run_batch(data)
+        one = time.time() - t0
+        reps = int(max(1, min(512, budget / max(one, 1e-3))))
+        t0 = time.time()
+        for _ in range(reps):
+            net.run_batch(data)
+        return reps * 128 / (time.time() - t0), reps
+
+    v_all, r_all = sample(cores, budget_s)
+    out = {'value': round(v_all, 1), 'unit': 'images/sec', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+           'sample': '%d training minibatches of 128 (fprop+bprop+update), same net and synthetic data' % r_all}
+    if gomp is not None:
+        v_one, r_one = sample(1, budget_one_s)
+        out['one_core'] = {'value': round(v_one, 1), 'unit': 'images/sec', 'cores': 1, 'sample': '%d training minibatches of 128' % r_one}
+        gomp.omp_set_num_threads(cores)
+    return out
 
 
 def main():
@@ -260,12 +287,18 @@ def main():
                                'frac': top['frac'], 'traffic': None, 'kernel': top['op'], 'avg_us': top['avg_us']}
             # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
             # under profiles/ with the gfx950 correction applied (they cannot be collected inside this process)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_by_op.json')
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic_by_op.json')
             if a.workload == 'deepid2' and mb == 128 and os.path.exists(pmc):
                 rec = json.load(open(pmc)).get(top['op'])
-                if rec:
+                # a record is only as good as the kernel it was taken from: it names the device symbol, which must still be
+                # in the library this run loaded (round 1 shipped a record of a kernel variant the tree no longer launched)
+                from cuda_convnet_amd import capi
+                blob = open(capi.LIB_PATH, 'rb').read()
+                if rec and all(sym.encode() in blob for sym in rec['kernel_symbols']):
                     out['roofline']['traffic'] = rec['traffic_bytes_per_launch']
                     out['roofline']['traffic_unit'] = 'bytes/launch (PMC, corrected); algorithmic %d' % rec['algorithmic_bytes_per_launch']
+                elif rec:
+                    out['roofline']['traffic_unit'] = 'stale PMC record dropped: %s not in this build' % ','.join(rec['kernel_symbols'])
             out['device_us_per_step'] = round(step_us, 1)
             # second half of BASELINE.json's metric: filterActs (conv / local forward) as a fraction of the fp32 MFMA peak
             conv_names = {l['name'] for l in layers if l['type'] in ('conv', 'local')}

@@ -19,6 +19,12 @@ struct BwdDataParams {
     float* targets;
     int N, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups, conv;
     float sT, sO;
+    // UNDO form: the image is the output of a 2x2 / stride 2 max pool over (2 imgY, 2 imgX) maps
+    const float* uActs;  // the pool's input  (C * 4 imgPixels, N)
+    const float* uMax;   // the pool's output (C * imgPixels, N)
+    float* uTarget;      // gradient w.r.t. the pool's input
+    int uNeuron;         // >= 0: times the gradient of the neuron that produced uActs
+    float uNa, uNb;
 };
 
 // A step = one (module, 16 filters) pair.  The steps a pixel needs are walked in batches of U: the loads of the
@@ -26,7 +32,12 @@ struct BwdDataParams {
 // round trip per batch instead of one per step.
 // KS = 2 / 4: that many waves share a pixel and take every KS-th 16-filter step; their accumulators are added through LDS.  With
 // ~1.3 waves per SIMD the plain form waits on memory 46 % of the time (profiles/r01_pmc_conv2_imgacts_sq_tcp.json).
-template <int CV, int NQ, bool VECN, int U, int KS = 1>
+// UNDO: the pixel's gradient does not go to `targets` but straight through the max pool below (whose windows do not overlap:
+// every pool input belongs to exactly one output) and the neuron under it -- what convLocalMaxUndo + the neuron's
+// gradient kernel would compute from `targets` in a second and third pass (layer.cu:734, :251), bit for bit.
+// UNDO: 0 off, 1 through the pool only, 2 through the pool and a relu (a run-time neuron switch per element was tried: the
+// unrolled epilogue grew to 28 k instructions and the launch lost more in instruction fetch than the fusion saved)
+template <int CV, int NQ, bool VECN, int U, int KS = 1, int UNDO = 0>
 __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
@@ -156,6 +167,51 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
                 for (int t = 0; t < NQ * 4; t++) acc[v][t] += red[wave / KS][o][v * NQ * 4 + t][lane];
     }
 
+    if constexpr (UNDO) {  // (VECN)
+        const int cX = 2 * p.imgX;
+#pragma unroll
+        for (int v = 0; v < CV; v++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const int n = n0 + 64 * q + 4 * j;
+                if (n >= p.N) continue;
+                f32x4 g[4], ma[4], im[4][4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {  // every load of this lane's 4 channels first
+                    const int c = min(c0 + 16 * v + 4 * kk + r, fc - 1);
+                    const size_t prow = ((size_t)(grp * fc + c) * imgPixels + px) * p.N + n;
+                    const size_t crow = ((size_t)(grp * fc + c) * 4 * imgPixels + (size_t)(2 * y) * cX + 2 * x) * p.N + n;
+                    if (p.sT != 0.f) g[r] = *reinterpret_cast<const f32x4*>(p.targets + prow);
+                    ma[r] = *reinterpret_cast<const f32x4*>(p.uMax + prow);
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        im[r][w] = *reinterpret_cast<const f32x4*>(p.uActs + crow + (size_t)((w >> 1) * cX + (w & 1)) * p.N);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int c = c0 + 16 * v + 4 * kk + r;
+                    if (c >= fc) continue;
+                    const size_t crow = ((size_t)(grp * fc + c) * 4 * imgPixels + (size_t)(2 * y) * cX + 2 * x) * p.N + n;
+                    f32x4 o;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) o[t] = p.sO * acc[v][q * 4 + t][r];
+                    if (p.sT != 0.f) o += p.sT * g[r];
+#pragma unroll
+                    for (int w = 0; w < 4; w++) {
+                        f32x4 out;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const float a = 0.f + (im[r][w][t] == ma[r][t] ? 1.f : 0.f) * o[t];  // (the undo kernel's accumulator)
+                            out[t] = 1.f * a;
+                            if (UNDO == 2) out[t] = neuron_grad(MCN_NEURON_RELU, out[t], im[r][w][t], 0.f, 0.f, 0.f);
+                        }
+                        *reinterpret_cast<f32x4*>(p.uTarget + crow + (size_t)((w >> 1) * cX + (w & 1)) * p.N) = out;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // D row 4*kk + r of tile v <-> channel c0 + 16v + 4kk + r ; col j of MFMA t <-> image n0+64q+4j+t
 #pragma unroll
     for (int v = 0; v < CV; v++) {
@@ -189,6 +245,23 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
 template <int CV, int NQ>
 static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipelined, int ksplit, hipStream_t s) {
     constexpr int U = CV + 4 * NQ <= 6 ? 4 : 2;  // steps per register set: (CV + 4 NQ) * 4 VGPRs each, two sets
+    if (p.uTarget) {  // (vecn: checked by the caller)
+#define MCN_UNDO_LAUNCH(UN)                                                                                               \
+    do {                                                                                                                  \
+        if (pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U, 1, UN>), grid, dim3(256), 0, s, p);                \
+        else if (ksplit) {                                                                                                \
+            if constexpr (CV == 1 && NQ == 1) {                                                                           \
+                grid.y = divup(p.imgY * p.imgX, 4 / ksplit);                                                              \
+                if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
+                else hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
+            }                                                                                                             \
+        } else hipLaunchKernelGGL((k_img_acts<CV, NQ, true, 1, 1, UN>), grid, dim3(256), 0, s, p);                        \
+    } while (0)
+        if (p.uNeuron == MCN_NEURON_RELU) MCN_UNDO_LAUNCH(2);
+        else MCN_UNDO_LAUNCH(1);
+#undef MCN_UNDO_LAUNCH
+        return;
+    }
     if (vecn && pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U>), grid, dim3(256), 0, s, p);
     else if (vecn && ksplit) {
         if constexpr (CV == 1 && NQ == 1) {
@@ -217,9 +290,16 @@ static void launch_bd1(const BwdDataParams& p, int nq, dim3 grid, bool vecn, boo
     else launch_bd2<CV, 1>(p, grid, vecn, pipelined, ksplit, s);
 }
 
+struct UndoArgs {
+    const float* acts;
+    const float* maxActs;
+    float* target;
+    int neuron;
+    float na, nb;
+};
 static int img_acts_impl(const float* hidActs, const float* filters, float* targets, int N, int imgY, int imgX,
                          int C, int F, int fs, int mY, int mX, int pad, int stride, int groups, int conv,
-                         float sT, float sO, void* stream) {
+                         float sT, float sO, void* stream, const UndoArgs* undo = nullptr) {
     // host asserts of _imgActs (img_acts.cu:900-940)
     MCN_REQUIRE(hidActs && filters && targets, "imgActs: null pointer");
     MCN_REQUIRE(N > 0 && imgY > 0 && imgX > 0 && C > 0 && F > 0 && fs > 0 && mY > 0 && mX > 0 && stride > 0 && groups > 0,
@@ -238,8 +318,17 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     p.hidActs = hidActs; p.filters = filters; p.targets = targets;
     p.N = N; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs; p.mY = mY; p.mX = mX;
     p.pad = pad; p.stride = stride; p.groups = groups; p.conv = conv; p.sT = sT; p.sO = sO;
+    p.uActs = nullptr; p.uMax = nullptr; p.uTarget = nullptr; p.uNeuron = -1; p.uNa = p.uNb = 0.f;
     const int fc = C / groups, imgPixels = imgY * imgX;
     const bool vecn = (N % 4 == 0) && (((uintptr_t)hidActs | (uintptr_t)targets) % 16 == 0);
+    if (undo) {
+        MCN_REQUIRE(undo->acts && undo->maxActs && undo->target, "imgActsMaxUndo: null pointer");
+        MCN_REQUIRE(vecn && (((uintptr_t)undo->acts | (uintptr_t)undo->maxActs | (uintptr_t)undo->target) % 16) == 0,
+                    "imgActsMaxUndo: numImages must be a multiple of 4 and the matrices 16-byte aligned");
+        MCN_REQUIRE(undo->neuron < 0 || undo->neuron == MCN_NEURON_IDENT || undo->neuron == MCN_NEURON_RELU,
+                    "imgActsMaxUndo: neuron %d is not built into this epilogue (none, ident, relu)", undo->neuron);
+        p.uActs = undo->acts; p.uMax = undo->maxActs; p.uTarget = undo->target; p.uNeuron = undo->neuron; p.uNa = undo->na; p.uNb = undo->nb;
+    }
     const int ct16 = divup(fc, 16);
     int CV = ct16 >= 4 && ct16 % 4 == 0 ? 4 : ct16 % 3 == 0 ? 3 : ct16 % 2 == 0 ? 2 : 1;
     int NQ = N > 64 ? 2 : 1;
@@ -280,4 +369,25 @@ MCN_API int mcn_local_img_acts(const float* hidActs, const float* filters, float
                                float scaleOutput, void* stream) {
     return img_acts_impl(hidActs, filters, targets, numImages, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize,
                          numModulesY, numModulesX, paddingStart, moduleStride, numGroups, 0, scaleTargets, scaleOutput, stream);
+}
+
+// imgActs of a conv / local layer whose input is a 2x2, stride 2, start 0 max pool over maps of exactly (2 imgSizeY, 2 imgSizeX)
+// pixels, continued through that pool and the neuron under it in the epilogue (see k_img_acts UNDO).  poolGrads: the pool
+// output's gradient matrix, READ when scaleTargets != 0 (another consumer of the pool wrote its share before), never written.
+MCN_API int mcn_img_acts_max_undo_supported(int numImages, int poolSizeX, int poolStart, int poolStride, int poolOutY, int poolOutX,
+                                            int poolImgY, int poolImgX, int neuron) {
+    return (neuron < 0 || neuron == MCN_NEURON_IDENT || neuron == MCN_NEURON_RELU) && numImages > 0 && numImages % 4 == 0 && poolSizeX == 2 && poolStride == 2 && poolStart == 0 && poolImgY == 2 * poolOutY &&
+           poolImgX == 2 * poolOutX;
+}
+MCN_API int mcn_img_acts_max_undo(const float* hidActs, const float* filters, const float* poolGrads, int numImages, int imgSizeY,
+                                  int imgSizeX, int numImgColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                  int paddingStart, int moduleStride, int numGroups, int conv, float scaleTargets, float scaleOutput,
+                                  const float* poolInput, const float* poolOutput, float* undoTarget, int neuron, float neuronA,
+                                  float neuronB, void* stream) {
+    MCN_REQUIRE(scaleTargets == 0.f || poolGrads, "imgActsMaxUndo: scaleTargets != 0 needs the pool's gradient matrix");
+    UndoArgs u{poolInput, poolOutput, undoTarget, neuron, neuronA, neuronB};
+    // (targets is only dereferenced when scaleTargets != 0; the alignment test wants a pointer either way)
+    return img_acts_impl(hidActs, filters, const_cast<float*>(poolGrads ? poolGrads : poolOutput), numImages, imgSizeY, imgSizeX, numImgColors,
+                         numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups, conv, scaleTargets,
+                         scaleOutput, stream, &u);
 }

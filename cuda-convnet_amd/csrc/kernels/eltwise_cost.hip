@@ -372,9 +372,20 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
 // Merge: lane group g (of 32) merges chunks g, g+32, ... of its 4 columns, the 32 groups are combined through LDS by 32
 // threads (one column each, fixed order) and M, S are broadcast through LDS.
 #define SMF4_ROWS 128
+// COST: the logreg cost of the same labels in the same launch (kLogregCost layer_kernels.cu:59-92).  The largest probability
+// of a column is expf(0)/S = 1/S exactly as the element that holds the maximum computes it, so every thread can count
+// how many of its entries equal it; the counts meet in per-column int atomics (exact in any order) and the thread that
+// holds the label's row leaves log p[label] and whether it is a maximum.  k_logreg_finish completes the cost.
+struct LogregFuse {
+    float* labelLogProbs;  // (numCases)
+    float* correctProbs;   // (numCases)
+    double* costOut;       // 2 accumulators
+    int* tieCnt;           // (numCases) zero between calls
+};
+template <bool COST>
 __global__ __launch_bounds__(256) void k_softmax_final4(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
                                                         int numOut, int numCases, int chunks, const float* __restrict__ labels,
-                                                        float* __restrict__ grad, float coeff) {
+                                                        float* __restrict__ grad, float coeff, LogregFuse lf) {
     __shared__ float shm[32][33], shs[32][33], shM[32], shS[32];
     const int cl = threadIdx.x & 7, g = threadIdx.x >> 3, col = blockIdx.x * 32 + 4 * cl;
     const bool live = col < numCases;  // numCases % 4 == 0
@@ -430,36 +441,95 @@ __global__ __launch_bounds__(256) void k_softmax_final4(const float* __restrict_
         shS[c] = S;
     }
     __syncthreads();
-    if (!live) return;
-    f32x4 M4, S4;
-    int lab[4];
+    if (!COST && !live) return;
+    f32x4 M4, S4, pmax;
+    int lab[4], ties[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         M4[t] = shM[4 * cl + t];
         S4[t] = shS[4 * cl + t];
-        lab[t] = grad ? (int)labels[col + t] : -1;
+        lab[t] = (labels && live) ? (int)labels[col + t] : -1;
+        pmax[t] = 1.0f / S4[t];
     }
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < SMF4_ROWS / 32; i++) {
-        const int r = r0 + g + 32 * i;
-        if (r < numOut) {
-            f32x4 pv, gv;
+        for (int i = 0; i < SMF4_ROWS / 32; i++) {
+            const int r = r0 + g + 32 * i;
+            if (r < numOut) {
+                f32x4 pv, gv;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                pv[t] = expf(v[i][t] - M4[t]) / S4[t];
-                gv[t] = coeff * ((lab[t] == r ? 1.f : 0.f) - pv[t]);
+                for (int t = 0; t < 4; t++) {
+                    pv[t] = expf(v[i][t] - M4[t]) / S4[t];
+                    gv[t] = coeff * ((lab[t] == r ? 1.f : 0.f) - pv[t]);
+                    if (COST) {
+                        ties[t] += pv[t] == pmax[t] ? 1 : 0;
+                        if (lab[t] == r) {
+                            lf.labelLogProbs[col + t] = logf(pv[t]);
+                            lf.correctProbs[col + t] = pv[t] == pmax[t] ? 1.f : 0.f;
+                        }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(p + (size_t)r * numCases + col) = pv;
+                if (grad) *reinterpret_cast<f32x4*>(grad + (size_t)r * numCases + col) = gv;
             }
-            *reinterpret_cast<f32x4*>(p + (size_t)r * numCases + col) = pv;
-            if (grad) *reinterpret_cast<f32x4*>(grad + (size_t)r * numCases + col) = gv;
         }
     }
+    if (!COST) return;
+    // ---- logreg cost
+    int(*shc)[33] = reinterpret_cast<int(*)[33]>(shm);  // (every thread is past its reads of shm: shM / shS came after a barrier)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; t++) shc[g][4 * cl + t] = ties[t];
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k++) c += shc[k][threadIdx.x];
+        const int cc = blockIdx.x * 32 + threadIdx.x;
+        if (c != 0 && cc < numCases) atomicAdd(&lf.tieCnt[cc], c);
+    }
 }
-
+// ... and one small block once the grid has drained: correctProbs from the hit flags and tie counts, the two cost scalars
+// summed in a fixed order, the counters cleared for the next call.  (A last-block-finishes form inside the launch above
+// needs a release fence per block, which on this part writes the XCD's L2 back: measured 12 -> 41 us for the launch.)
+__global__ __launch_bounds__(256) void k_logreg_finish(LogregFuse lf, int numCases) {
+    __shared__ double sh0[256], sh1[256];
+    double a0 = 0, a1 = 0;
+    for (int c = threadIdx.x; c < numCases; c += 256) {
+        const float lp = lf.labelLogProbs[c], hit = lf.correctProbs[c];
+        const int cnt = lf.tieCnt[c];
+        const float cp = hit != 0.f ? 1.0f / (float)cnt : 0.f;
+        lf.correctProbs[c] = cp;
+        lf.tieCnt[c] = 0;
+        a0 += (double)lp;
+        a1 += 1.0 - (double)cp;
+    }
+    sh0[threadIdx.x] = a0;
+    sh1[threadIdx.x] = a1;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {  // fixed tree
+        if ((int)threadIdx.x < w) {
+            sh0[threadIdx.x] += sh0[threadIdx.x + w];
+            sh1[threadIdx.x] += sh1[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&lf.costOut[0], -sh0[0]);
+        atomicAdd(&lf.costOut[1], sh1[0]);
+    }
+}
+static bool softmax_final4_usable(const float* x, const float* probs, const float* part, const float* grad, int numOut, int numCases) {
+    return numCases % 4 == 0 && al16(x) && al16(probs) && al16(part) && (!grad || al16(grad)) && divup(numOut, SMF4_ROWS) <= 65535;
+}
 static int softmax_final_launch(const float* x, float* probs, const float* part, int numOut, int numCases, int chunks, const float* labels,
-                                float* grad, float coeff, hipStream_t s) {
-    if (numCases % 4 == 0 && al16(x) && al16(probs) && al16(part) && (!grad || al16(grad)) && divup(numOut, SMF4_ROWS) <= 65535)
-        hipLaunchKernelGGL(k_softmax_final4, dim3(divup(numCases, 32), divup(numOut, SMF4_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
-                           numCases, chunks, labels, grad, coeff);
+                                float* grad, float coeff, hipStream_t s, const LogregFuse* lf = nullptr) {
+    const dim3 grid4(divup(numCases, 32), divup(numOut, SMF4_ROWS));
+    if (lf)  // (the caller has checked softmax_final4_usable)
+        hipLaunchKernelGGL((k_softmax_final4<true>), grid4, dim3(256), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, *lf);
+    else if (softmax_final4_usable(x, probs, part, grad, numOut, numCases))
+        hipLaunchKernelGGL((k_softmax_final4<false>), grid4, dim3(256), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff,
+                           LogregFuse{});
     else
         hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
                            numCases, chunks, labels, grad, coeff);
@@ -494,6 +564,58 @@ MCN_API int mcn_softmax_from_part(const float* x, float* probs, const float* lab
         return MCN_EWORKSPACE;
     }
     return softmax_final_launch(x, probs, (const float*)part, numOut, numCases, chunks, labels, gradTarget, coeff, (hipStream_t)stream);
+}
+// softmax (+ optional logreg gradient) + logreg cost in the stage-2 launch.  `part` != NULL: stage 1 is already there
+// (mcn_gemm_bias_neuron_softmax_part), else it runs first into `workspace`.  `state`: mcn_softmax_logreg_cost_state_bytes
+// bytes of device memory, zero before the first call and owned by these calls (left zero by each).
+MCN_API size_t mcn_softmax_logreg_cost_state_bytes(int numCases) { return ((size_t)numCases + 4) * sizeof(int); }
+// the second, one-block launch of mcn_softmax_logreg_cost(finish = 0) at a time (and on a stream) of the caller's choosing
+MCN_API int mcn_softmax_logreg_cost_finish(float* labelLogProbs, float* correctProbs, double* costOut, void* state, size_t stateBytes,
+                                           int numCases, void* stream) {
+    MCN_REQUIRE(labelLogProbs && correctProbs && costOut && state && numCases > 0, "softmaxLogregCostFinish: bad argument");
+    MCN_REQUIRE(stateBytes >= mcn_softmax_logreg_cost_state_bytes(numCases), "softmaxLogregCostFinish: state buffer too small");
+    LogregFuse lf;
+    lf.labelLogProbs = labelLogProbs;
+    lf.correctProbs = correctProbs;
+    lf.costOut = costOut;
+    lf.tieCnt = (int*)state;
+    hipLaunchKernelGGL(k_logreg_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, lf, numCases);
+    return MCN_LAUNCH_CHECK("logreg finish");
+}
+MCN_API int mcn_softmax_logreg_cost_supported(int numOut, int numCases) {
+    return numOut > 0 && numCases > 0 && numCases % 4 == 0 && divup(numOut, SMF4_ROWS) <= 65535 && divup(numOut, SM_ROWS) <= 65535;
+}
+MCN_API int mcn_softmax_logreg_cost(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
+                                    int numCases, const void* part, size_t partBytes, void* workspace, size_t workspaceBytes,
+                                    float* labelLogProbs, float* correctProbs, double* costOut, void* state, size_t stateBytes,
+                                    int finish, void* stream) {
+    MCN_REQUIRE(x && probs && labels && labelLogProbs && correctProbs && costOut && state, "softmaxLogregCost: null pointer");
+    MCN_REQUIRE(mcn_softmax_logreg_cost_supported(numOut, numCases), "softmaxLogregCost: numCases must be a multiple of 4");
+    MCN_REQUIRE(stateBytes >= mcn_softmax_logreg_cost_state_bytes(numCases), "softmaxLogregCost: state buffer too small");
+    const int chunks = divup(numOut, SM_ROWS);
+    const size_t need = mcn_softmax_workspace_bytes(numOut, numCases);
+    hipStream_t s = (hipStream_t)stream;
+    const void* stage1 = part;
+    if (part) {
+        MCN_REQUIRE(partBytes >= need, "softmaxLogregCost: partial buffer too small");
+    } else {
+        if (!workspace || workspaceBytes < need) {
+            mcn_set_error("softmaxLogregCost: workspace %zu < %zu bytes", workspaceBytes, need);
+            return MCN_EWORKSPACE;
+        }
+        hipLaunchKernelGGL(k_softmax_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
+        stage1 = workspace;
+    }
+    MCN_REQUIRE(softmax_final4_usable(x, probs, (const float*)stage1, gradTarget, numOut, numCases), "softmaxLogregCost: pointers must be 16-byte aligned");
+    LogregFuse lf;
+    lf.labelLogProbs = labelLogProbs;
+    lf.correctProbs = correctProbs;
+    lf.costOut = costOut;
+    lf.tieCnt = (int*)state;
+    const int rc = softmax_final_launch(x, probs, (const float*)stage1, numOut, numCases, chunks, labels, gradTarget, coeff, s, &lf);
+    if (rc != MCN_OK || !finish) return rc;
+    hipLaunchKernelGGL(k_logreg_finish, dim3(1), dim3(256), 0, s, lf, numCases);
+    return MCN_LAUNCH_CHECK("logreg finish");
 }
 MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
     return softmax_impl(x, probs, nullptr, nullptr, 0.f, numOut, numCases, workspace, workspaceBytes, stream);

@@ -695,7 +695,10 @@ int fc_fprop_multi_launch(const float* const* W, const float* const* X, const in
     p.bias = bias; p.Y = Y; p.M = M; p.N = N; p.neuron = neuron; p.fa = na; p.fb = nb; p.fbeta = beta;
     dim3 grid(divup(N, 16), divup(M, 16));
     MCN_REQUIRE(grid.y <= 65535, "fcFpropMulti: grid too large");
-    hipLaunchKernelGGL((k_fc_fprop_multi<6>), grid, dim3(512), 0, s, p);
+    // a wave's whole share in two register sets of 9 steps when it fits (fc5: 139 steps / 8 waves = 18): every load is in
+    // flight before the first MFMA, one round trip per wave; longer reductions walk batches of 6
+    if ((p.totalSteps + 7) / 8 <= 18) hipLaunchKernelGGL((k_fc_fprop_multi<9>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_fc_fprop_multi<6>), grid, dim3(512), 0, s, p);
     return MCN_LAUNCH_CHECK("fcFpropMulti");
 }
 

@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "common.h"
+#include <chrono>
 
 static thread_local char g_err[512] = "";
 
@@ -23,6 +24,13 @@ int mcn_check_hip(hipError_t e, const char* what) {
 static thread_local size_t t_launches = 0;
 int mcn_launch_check(const char* what) {
     t_launches++;
+    // MCN_LAUNCH_DELAY_NS (diagnostic): busy-wait after every launch -- if a step slows down by launches x delay the step
+    // is bound by the submitting threads, if it does not the device is
+    static const long delayNs = getenv("MCN_LAUNCH_DELAY_NS") ? atol(getenv("MCN_LAUNCH_DELAY_NS")) : 0;
+    if (delayNs > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() < delayNs) {}
+    }
     return mcn_check_hip(hipGetLastError(), what);
 }
 MCN_API size_t mcn_launch_count(void) { return t_launches; }
@@ -104,6 +112,16 @@ MCN_API int mcn_event_record(void* event, void* stream) {
     return mcn_check_hip(hipEventRecord((hipEvent_t)event, (hipStream_t)stream), "hipEventRecord");
 }
 MCN_API int mcn_event_sync(void* event) { return mcn_check_hip(hipEventSynchronize((hipEvent_t)event), "hipEventSynchronize"); }
+// 1: everything recorded before the event has completed; 0: not yet; < 0: error
+MCN_API int mcn_event_query(void* event) {
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return mcn_check_hip(e, "hipEventQuery");
+}
 MCN_API int mcn_stream_wait_event(void* stream, void* event) {
     return mcn_check_hip(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0), "hipStreamWaitEvent");
 }

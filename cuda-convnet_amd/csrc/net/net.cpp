@@ -23,9 +23,24 @@ int timedEventRecord(void* e, void* s) {
     g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
+static thread_local int t_stream = 0;  // which stream this submitting thread feeds: 0 main, 1 side, 2 exchange, 3 copy
+// Which submitting threads poll an event themselves (hipEventQuery) instead of queueing a wait on their stream: bit 0 the
+// main thread, bit 1 the side thread.  A wait queued on a stream for an event that has not fired yet costs the waiting
+// queue ~10 us after it fires (measured on MI355X / ROCm 7.2: DeepID2 step 0.315 ms with queued waits, 0.280 ms when the
+// side thread polls -- it has nothing else to do, and launches the moment the main stream's kernel has finished).
+// Default: the side thread polls.  MCN_HOST_WAIT overrides (0: every wait queued).
+static const int g_hostWaitMask = getenv("MCN_HOST_WAIT") ? atoi(getenv("MCN_HOST_WAIT")) : 2;
+static bool g_noHostWait = false;  // (stream capture in progress: events cannot be queried)
 int timedStreamWait(void* s, void* e) {
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = mcn_stream_wait_event(s, e);
+    int rc = MCN_OK;
+    if (!g_noHostWait && t_stream <= 1 && ((g_hostWaitMask >> t_stream) & 1)) {
+        int q;
+        while ((q = mcn_event_query(e)) == 0) {}
+        if (q < 0) rc = q;
+    } else {
+        rc = mcn_stream_wait_event(s, e);
+    }
     g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
@@ -536,6 +551,21 @@ void LocalLayer::fpropActs(int i, float scaleTargets, PassType) {  // layer.cu:4
 }
 
 void LocalLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {  // layer.cu:498-513, :566-575
+    // input = a max pool with non-overlapping windows, and every other consumer of that pool has already added its share:
+    // the gradient goes through the pool (and the neuron under it) in the epilogue, never to the pool's own gradient matrix
+    if (auto* pl = dynamic_cast<PoolLayer*>(_prev[i])) {
+        if (pl->rcvdB() + 1 == pl->numGradProducersNext() && pl->prev()[0]->isGradConsumer() &&
+            pl->undoFusable(_net->numCases(), (int)_channels[i], (int)_imgSizeY[i], (int)_imgSizeX[i])) {
+            NeuronLayer* r = pl->fusedNeuronGrad;
+            chk(mcn_img_acts_max_undo(v, _weights[i]->W(), scaleTargets != 0 ? pl->getActsGrad() : nullptr, _net->numCases(), (int)_imgSizeY[i],
+                                      (int)_imgSizeX[i], (int)_channels[i], _filters, (int)_filterSize[i], _modulesY, _modulesX,
+                                      (int)_padding[i], (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, scaleTargets, 1.f,
+                                      pl->prev()[0]->getActs(), pl->getActs(), pl->prev()[0]->getActsGrad(), r ? r->spec.type : -1,
+                                      r ? r->spec.a : 0.f, r ? r->spec.b : 0.f, _net->stream()), "imgActs + max undo");
+            pl->undoDoneAbove = true;
+            return;
+        }
+    }
     auto fn = _conv ? mcn_conv_img_acts : mcn_local_img_acts;
     chk(fn(v, _weights[i]->W(), _prev[i]->getActsGrad(), _net->numCases(), (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i],
            _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], scaleTargets, 1.f,
@@ -581,6 +611,9 @@ void SoftmaxLayer::allocate(int maxCases) {
     Layer::allocate(maxCases);
     partBytes = mcn_softmax_workspace_bytes(_outputs, maxCases);
     part.ensure((partBytes + 3) / 4);
+    costStateBytes = mcn_softmax_logreg_cost_state_bytes(maxCases);
+    costState.ensure((costStateBytes + 3) / 4);
+    chk(mcn_memset(costState.p, 0, costStateBytes, _net->stream()), "softmax cost state");
 }
 
 void SoftmaxLayer::fpropActs(int, float, PassType pt) {
@@ -593,6 +626,19 @@ void SoftmaxLayer::fpropActs(int, float, PassType pt) {
     CostLayer* cost = _next.size() == 1 && _next[0]->type() == "cost.logreg" ? static_cast<CostLayer*>(_next[0]) : nullptr;
     if (cost && pt != PASS_TEST && _net->fusion() && cost->coeff() != 0 && _prev[0]->isGradConsumer() && _prev[0]->next().size() == 1) {
         float* labels = cost->prev()[0]->getActs();
+        static const bool noCostFusion = getenv("MCN_NO_LOGREG_FUSION") != nullptr;
+        LogregCostLayer* lc = static_cast<LogregCostLayer*>(cost);
+        if (!noCostFusion && mcn_softmax_logreg_cost_supported(_outputs, _net->numCases()) && lc->dCost) {
+            // ... and the cost itself: the last block of the same launch finishes it (no cost kernels at the end of the step)
+            chk(mcn_softmax_logreg_cost(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(),
+                                        havePart ? part.p : nullptr, partBytes, _net->workspace(), _net->workspaceBytes(), lc->logProbsBuf(),
+                                        lc->correctBuf(), lc->dCost, costState.p, costStateBytes, 0, _net->stream()), "softmax + logreg grad + cost");
+            lc->costDoneBySoftmax = true;
+            lc->softmaxState = costState.p;
+            lc->softmaxStateBytes = costStateBytes;
+            _gradFused = true;
+            return;
+        }
         if (havePart)
             chk(mcn_softmax_from_part(_inputs[0], _acts, labels, _prev[0]->getActsGrad(), cost->coeff(), _outputs, _net->numCases(), part.p,
                                       partBytes, _net->stream()), "softmax stage 2 + logreg grad");
@@ -679,7 +725,19 @@ void PoolLayer::fpropActs(int, float, PassType) {
                        _max ? 0 : 1, _net->stream()), "pool");
 }
 
+bool PoolLayer::undoFusable(int numCases, int channels, int outY, int outX) const {
+    static const bool off = getenv("MCN_NO_UNDO_FUSION") != nullptr;
+    return !off && _net->fusion() && _max && channels == _channels && outY == _outputsY && outX == _outputsX &&
+           (fusedNeuronGrad || _prev[0]->numGradProducersNext() == 1) &&
+           mcn_img_acts_max_undo_supported(numCases, _sizeX, _start, _stride, _outputsY, _outputsX, _imgSizeY, _imgSizeX,
+                                           fusedNeuronGrad ? fusedNeuronGrad->spec.type : -1) == 1;
+}
+
 void PoolLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
+    if (undoDoneAbove) {  // the last consumer's backward-data product wrote the gradient of this pool's input itself
+        undoDoneAbove = false;
+        return;
+    }
     float* tgt = _prev[0]->getActsGrad();
     const int n = _net->numCases();
     if (!_max) {
@@ -773,6 +831,14 @@ size_t LogregCostLayer::workspaceBytes(int maxCases) { return mcn_logreg_cost_wo
 
 void LogregCostLayer::fpropActs(int i, float, PassType) {  // layer.cu:969-981
     if (i != 0) return;
+    if (costDoneBySoftmax) {  // the softmax below left log p[label], hit flags and tie counts (this pass): one small block finishes
+        costDoneBySoftmax = false;
+        const int nc = _net->numCases();
+        _net->deferLateWork([this, nc] {
+            chk(mcn_softmax_logreg_cost_finish(_acts, _aux.p, dCost, softmaxState, softmaxStateBytes, nc, _net->stream()), "logreg cost");
+        });
+        return;
+    }
     // the cost value is off the critical path (nothing downstream reads it): side stream
     float *labels = _inputs[0], *probs = _inputs[1];
     const int n = _net->numCases();  // (captured now: in a test pass the closure runs while the NEXT minibatch is being set up)
@@ -923,7 +989,6 @@ void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  /
 }
 
 // ============================================================================ Uploader
-static thread_local int t_stream = 0;  // which stream this submitting thread feeds: 0 main, 1 side, 2 exchange, 3 copy
 
 void Uploader::start(int deviceID) {
     chk(mcn_stream_create(&_stream), "copy stream");
@@ -1746,6 +1811,7 @@ void ConvNet::captureStep(int miniIdx, StepGraph& g) {
     joinGradWork();  // nothing may be pending on the side stream when the capture starts
     chk(mcn_graph_begin_capture(_stream), "begin capture");
     _capturing = true;
+    g_noHostWait = true;
     try {
         fprop(miniIdx, PASS_TRAIN);
         bprop(PASS_TRAIN);
@@ -1753,12 +1819,15 @@ void ConvNet::captureStep(int miniIdx, StepGraph& g) {
         joinGradWork();
     } catch (...) {
         _capturing = false;
+    g_noHostWait = false;
+        g_noHostWait = false;
         void* dead = nullptr;
         mcn_graph_end_capture(_stream, &dead, nullptr);
         mcn_graph_destroy(dead);
         throw;
     }
     _capturing = false;
+    g_noHostWait = false;
     chk(mcn_graph_end_capture(_stream, &g.exec, &g.nodes), "end capture");
     g.data = _curData;
     g.numCases = _numCases;

@@ -245,6 +245,8 @@ class SoftmaxLayer : public Layer {
     DBuf part;               // stage-1 partials written by the producing FC layer's forward product
     size_t partBytes = 0;
     bool partReady = false;  // ... for the pass in flight
+    DBuf costState;          // tie counters + ticket of mcn_softmax_logreg_cost (zero between calls)
+    size_t costStateBytes = 0;
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
@@ -283,6 +285,10 @@ class PoolLayer : public Layer {
     PoolLayer(ConvNet* net, const Params& p);
     NeuronLayer* fusedNeuronGrad = nullptr;  // relu(-like) below a max pool: gradient applied in the undo kernel
     bool isMax() const { return _max; }
+    // the conv / local layer above may send its gradient straight through this pool (mcn_img_acts_max_undo) when it is the
+    // last of the pool's consumers to report: undoFusable = the windows tile the maps, this pool alone feeds the layer below
+    bool undoFusable(int numCases, int channels, int outY, int outX) const;
+    bool undoDoneAbove = false;  // ... for the pass in flight: bpropActs has nothing left to do
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
@@ -333,6 +339,12 @@ class LogregCostLayer : public CostLayer {
     int numCostValues() const override { return 2; }
     size_t workspaceBytes(int maxCases) override;
     size_t actsElems(int n) const override { return (size_t)n; }
+    // a softmax below may finish this cost in its own launch (mcn_softmax_logreg_cost): the buffers it fills
+    float* logProbsBuf() { return _ownActs.p; }
+    float* correctBuf() { return _aux.p; }
+    bool costDoneBySoftmax = false;  // ... for the pass in flight
+    void* softmaxState = nullptr;    // that softmax's counters (mcn_softmax_logreg_cost_finish)
+    size_t softmaxStateBytes = 0;
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;

@@ -78,6 +78,8 @@ int mcn_event_destroy(void* event);
 int mcn_event_record(void* event, void* stream);
 int mcn_event_sync(void* event);
 int mcn_stream_wait_event(void* stream, void* event);
+/* hipEventQuery: 1 = complete, 0 = not yet, < 0 = error */
+int mcn_event_query(void* event);
 int mcn_event_elapsed_ms(float* ms, void* start, void* stop);
 
 /* Step graphs (no counterpart in the reference, whose step is ~45 launches and several blocking copies per minibatch):
@@ -123,6 +125,22 @@ int mcn_local_img_acts(const float* hidActs, const float* filters, float* target
                        int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
                        int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
                        int numGroups, float scaleTargets, float scaleOutput, void* stream);
+
+/* imgActs + MaxPoolLayer::bpropActs (layer.cu:734, convLocalMaxUndo conv_util.cuh) + NeuronLayer::bpropActs (layer.cu:251)
+ * in one launch, for a conv / local layer (conv = 1 / 0) whose input is a max pool with sizeX 2, stride 2, start 0 over maps of
+ * exactly (2 imgSizeY, 2 imgSizeX) pixels (mcn_img_acts_max_undo_supported): the gradient of each pool output goes from the
+ * accumulators straight to the pool input it came from,
+ *   undoTarget[c, 2y+i, 2x+j, n] = neuronGrad( (poolInput[c,2y+i,2x+j,n] == poolOutput[c,y,x,n]) * g[c,y,x,n] ),
+ *   g = scaleTargets*poolGrads + scaleOutput*imgActs(hidActs, filters)
+ * -- bit for bit what the three separate calls leave in undoTarget.  poolGrads (C*imgSizeY*imgSizeX, numImages) is only read,
+ * and only when scaleTargets != 0 (may be NULL otherwise); neuron: -1 (none), MCN_NEURON_IDENT or MCN_NEURON_RELU. */
+int mcn_img_acts_max_undo_supported(int numImages, int poolSizeX, int poolStart, int poolStride, int poolOutY, int poolOutX,
+                                    int poolImgY, int poolImgX, int neuron);
+int mcn_img_acts_max_undo(const float* hidActs, const float* filters, const float* poolGrads, int numImages, int imgSizeY,
+                          int imgSizeX, int numImgColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                          int paddingStart, int moduleStride, int numGroups, int conv, float scaleTargets, float scaleOutput,
+                          const float* poolInput, const float* poolOutput, float* undoTarget, int neuron, float neuronA,
+                          float neuronB, void* stream);
 
 /* convWeightActs (cudaconv2.cuh:67-70, weight_acts.cu:955-964): targets
  * ((modules/partialSum)*filterChannels*filterPixels, numFilters); partialSum <= 0 means all modules.
@@ -291,6 +309,24 @@ int mcn_softmax_logreg_grad(const float* x, float* probs, const float* labels, f
 size_t mcn_logreg_cost_workspace_bytes(int numOut, int numCases);
 int mcn_logreg_cost(const float* labels, const float* probs, float* labelLogProbs, float* correctProbs,
                     int numOut, int numCases, double* costOut, void* workspace, size_t workspaceBytes, void* stream);
+/* SoftmaxLayer::fpropActs + LogregCostLayer::fpropActs (layer.cu:585-595, 969-981) without a second pass over the
+ * probabilities: the softmax launch also writes, optionally, the logreg gradient through the softmax (gradTarget, may be
+ * NULL), log p[label], and counts the entries tied at each column's maximum in integer atomics; a one-block launch then
+ * finishes labelLogProbs / correctProbs / costOut (the values of mcn_logreg_cost).  finish != 0: that launch follows at
+ * once; finish == 0: the caller issues mcn_softmax_logreg_cost_finish later (any stream ordered after this call), and
+ * labelLogProbs / correctProbs / costOut are defined only after it.  part != NULL: stage 1 was left by
+ * mcn_gemm_bias_neuron_softmax_part; else it runs first into workspace (mcn_softmax_workspace_bytes).  state:
+ * mcn_softmax_logreg_cost_state_bytes(numCases) bytes of device memory, zero before the first call, used by one
+ * call (+ its finish) at a time and left zero.  Needs numCases % 4 == 0 (mcn_softmax_logreg_cost_supported) and
+ * 16-byte aligned matrices. */
+size_t mcn_softmax_logreg_cost_state_bytes(int numCases);
+int mcn_softmax_logreg_cost_supported(int numOut, int numCases);
+int mcn_softmax_logreg_cost(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
+                            int numCases, const void* part, size_t partBytes, void* workspace, size_t workspaceBytes,
+                            float* labelLogProbs, float* correctProbs, double* costOut, void* state, size_t stateBytes,
+                            int finish, void* stream);
+int mcn_softmax_logreg_cost_finish(float* labelLogProbs, float* correctProbs, double* costOut, void* state, size_t stateBytes,
+                                   int numCases, void* stream);
 /* computeLogregGrad (layer_kernels.cu:241-263) */
 int mcn_logreg_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
                     float coeff, void* stream);

@@ -870,3 +870,90 @@ def test_softmax_with_fused_logreg_grad():
     call('mcn_softmax_logreg_grad', dev(x), p2, dev(labels), g2, 0.7, K, N, ws, nb, None)
     assert np.array_equal(p1.numpy(), p2.numpy())
     assert np.array_equal(g1.numpy(), g2.numpy())
+
+
+@pytest.mark.parametrize('K,N', [(10575, 128), (4213, 96), (257, 4), (10, 260)])
+def test_softmax_with_fused_logreg_cost(K, N):
+    """mcn_softmax_logreg_cost == mcn_softmax_logreg_grad followed by mcn_logreg_cost: probabilities, gradient, log p[label]
+    and correctProbs bit for bit (ties at the maximum included), the two cost scalars to the last digits of a double --
+    on two calls in a row over the same state buffer, the second with other data."""
+    rng = np.random.default_rng(44)
+    nb = ws_bytes('mcn_softmax_workspace_bytes', K, N)
+    ws = capi.workspace(nb)
+    sb = ws_bytes('mcn_softmax_logreg_cost_state_bytes', N)
+    state = capi.workspace(sb)
+    call('mcn_memset', state, 0, sb, None)
+    assert capi.lib().raw('mcn_softmax_logreg_cost_supported')(K, N) == 1
+    for rep in range(2):
+        x = mk(rng, K, N, scale=2.0)
+        labels = rng.integers(0, K, (1, N)).astype(np.float32)
+        k0, k1 = int(labels[0, 0]), int(labels[0, 1])
+        x[:, 0] = -1.0          # two maxima, the label one of them: correctProbs 0.5
+        x[k0, 0] = x[(k0 + 3) % K, 0] = 2.5
+        x[:, 1] = 0.25          # every entry tied: 1/K
+        x[(k1 + 1) % K, 2] = 9.0  # a clear maximum (that is the label only by chance)
+        x[int(labels[0, 3]), 3] = 11.0  # the label is the single maximum
+        p1, p2, g1, g2 = (dev_empty((K, N), np.nan) for _ in range(4))
+        lp1, cp1, lp2, cp2 = (dev_empty((1, N), np.nan) for _ in range(4))
+        c1, c2 = dev_double(2), dev_double(2)
+        call('mcn_softmax_logreg_grad', dev(x), p1, dev(labels), g1, 0.7, K, N, ws, nb, None)
+        call('mcn_logreg_cost', dev(labels), p1, lp1, cp1, K, N, c1, ws, nb, None)
+        call('mcn_softmax_logreg_cost', dev(x), p2, dev(labels), g2, 0.7, K, N, None, 0, ws, nb, lp2, cp2, c2, state, sb, rep, None)
+        if rep == 0:  # the one-block launch on its own
+            call('mcn_softmax_logreg_cost_finish', lp2, cp2, c2, state, sb, N, None)
+        assert np.array_equal(p1.numpy(), p2.numpy())
+        assert np.array_equal(g1.numpy(), g2.numpy())
+        assert np.array_equal(lp1.numpy(), lp2.numpy())
+        assert np.array_equal(cp1.numpy(), cp2.numpy())
+        cp = cp2.numpy()[0]
+        assert cp[0] == 0.5 and cp[1] == np.float32(1.0) / np.float32(K) and cp[3] == 1.0
+        a, b = c1.numpy(), c2.numpy()
+        assert np.all(np.abs(a - b) <= 1e-12 * np.abs(a)), (a, b)
+        # against the oracle, on the probabilities the device produced
+        wlp, wcp = O.logreg_cost(labels, p2.numpy(), K, N)
+        assert np.array_equal(cp2.numpy(), wcp)
+        close(lp2.numpy(), wlp, rtol=2e-6, what='logprob')
+
+
+@pytest.mark.parametrize('N', [128, 96, 4])
+@pytest.mark.parametrize('sT', [0.0, 1.0])
+@pytest.mark.parametrize('name', ['conv2', 'conv2_39x31', 'local3', 'local3_39x31', 'local4', 'local4_39x31', 'conv2_plus', 'local3_plus',
+                                  'local4_plus', 'groups2'])
+def test_img_acts_through_max_pool_and_neuron(name, sT, N):
+    """mcn_img_acts_max_undo == imgActs into the pool's gradient matrix, then mcn_local_max_undo_neuron, bit for bit (relu under a
+    2x2 / stride 2 pool whose windows tile the maps: the DeepID stacks), with and without another consumer's share already in
+    the pool's gradient; the unfused chain itself is checked against the oracle."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(45)
+    hid = mk(rng, F * mY * mX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    cY, cX = 2 * imgY, 2 * imgX
+    acts = np.maximum(mk(rng, C_ * cY * cX, N), 0)  # relu outputs: plenty of exact zeros, so ties inside windows occur
+    pooled = acts.reshape(C_, imgY, 2, imgX, 2, N).max(axis=(2, 4)).reshape(C_ * imgY * imgX, N)
+    share = mk(rng, C_ * imgY * imgX, N)
+    assert capi.lib().raw('mcn_img_acts_max_undo_supported')(N, 2, 0, 2, imgY, imgX, cY, cX, 1) == 1
+    for neuron in (1, -1):  # MCN_NEURON_RELU / none
+        d_pg = dev(share)
+        call('mcn_conv_img_acts' if conv else 'mcn_local_img_acts', dev(hid), dev(W), d_pg, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride,
+             groups, sT, 1.0, None)
+        d_want = dev_empty(acts.shape, np.nan)
+        if neuron >= 0:
+            call('mcn_local_max_undo_neuron', dev(acts), d_pg, dev(pooled), d_want, N, C_, cY, cX, 2, 0, 2, imgY, imgX, neuron, 0.0, 0.0, None)
+        else:
+            call('mcn_local_max_undo', dev(acts), d_pg, dev(pooled), d_want, N, C_, cY, cX, 2, 0, 2, imgY, imgX, 0.0, 1.0, None)
+        d_got = dev_empty(acts.shape, np.nan)
+        call('mcn_img_acts_max_undo', dev(hid), dev(W), dev(share) if sT else None, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups,
+             1 if conv else 0, sT, 1.0, dev(acts), dev(pooled), d_got, neuron, 0.0, 0.0, None)
+        got, want = d_got.numpy(), d_want.numpy()
+        assert np.all(np.isfinite(got))
+        assert np.array_equal(got, want), '%s N=%d sT=%g neuron=%d: %d entries differ' % (name, N, sT, neuron, int((got != want).sum()))
+    # the unfused chain against the oracle (once per geometry)
+    if sT == 0.0 and N == 96:
+        wg = O.img_acts(hid, W, N, conv=conv, **geo_kw(g))
+        wu = O.local_max_undo(acts, wg, pooled, N, C_, cY, cX, 2, 0, 2, imgY, imgX)
+        wu = wu * (acts > 0)
+        d_got = dev_empty(acts.shape, np.nan)
+        call('mcn_img_acts_max_undo', dev(hid), dev(W), None, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 1 if conv else 0, 0.0, 1.0,
+             dev(acts), dev(pooled), d_got, 1, 0.0, 0.0, None)
+        close(d_got.numpy(), wu, what='imgActs + max undo + relu grad')

@@ -78,6 +78,15 @@ def main():
         report(name + ' filterActs+bias+relu', (lambda: call('mcn_filter_acts_bias_neuron', img, W, b, out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, int(conv), 0 if conv else 1, 1, 0.0, 0.0, None)), flops, nbytes)
         if C_ > 3:
             report(name + ' imgActs', (lambda: call(pre + 'img_acts', hid, W, dimg, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, 0.0, 1.0, None)), flops, nbytes)
+        if C_ > 3:  # ... and on through a 2x2 max pool + relu below (the DeepID stacks)
+            cY, cX = 2 * imgY, 2 * imgX
+            acts = dev(np.maximum(rng.standard_normal((C_ * cY * cX, N)), 0).astype(np.float32))
+            pooled = dev_empty((C_ * imgY * imgX, N))
+            call('mcn_local_pool', acts, pooled, N, C_, cY, cX, 2, 0, 2, imgY, imgX, 0, None)
+            dact = dev_empty((C_ * cY * cX, N))
+            ub = 4.0 * (2 * acts.nbytes / 4 + 2 * pooled.nbytes / 4)
+            report(name + ' maxUndo+relu', (lambda: call('mcn_local_max_undo_neuron', acts, dimg, pooled, dact, N, C_, cY, cX, 2, 0, 2, imgY, imgX, 1, 0.0, 0.0, None)), 0.0, ub)
+            report(name + ' imgActs+maxUndo+relu', (lambda: call('mcn_img_acts_max_undo', hid, W, None, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, int(conv), 0.0, 1.0, acts, pooled, dact, 1, 0.0, 0.0, None)), flops, nbytes + ub)
         if conv:
             report(name + ' weightActs(reduced)', (lambda: call('mcn_conv_weight_acts_reduced', img, hid, dW, ws, ws.nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, 0.0, 1.0, None)), flops, nbytes)
         else:
