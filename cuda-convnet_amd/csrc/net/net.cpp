@@ -320,7 +320,8 @@ float WeightLayer::gradScale(float eps, PassType pt) const {
 void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
     // two pieces of side-stream work: they start at once next to this layer's backward-data kernels, except for the
     // last weight layer of the pass, which has nothing left to hide behind and is split over both streams
-    const bool last = _net->lastWeightLayerOfPass();
+    const bool last = _net->lastWeightLayerOfPass(this);
+    if (last && pt == PASS_TRAIN) _net->earlyUpdate();  // (queued ahead of this layer's own pieces, see there)
     _net->deferSideWork([this, v, pt] {
         if (_biases->eps() > 0) {
             ProfScope ps(_net, _name, "bpropBiases");
@@ -1470,6 +1471,7 @@ void ConvNet::allocate(int maxCases) {
         }
     }
     _sgdCount = (int)items.size();
+    _splitPlans = false;
     if (_sgdCount > 0) {
         const size_t pb = mcn_sgd_plan_bytes(_sgdCount);
         _sgdPlan.ensure((pb + 3) / 4);
@@ -1589,7 +1591,57 @@ void ConvNet::waitSideSubmitted(long ticket) {
     if (ticket > 0) _side.wait(ticket);
 }
 
-bool ConvNet::lastWeightLayerOfPass() { return ++_wlSeen == _wlPerPass; }
+bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
+    _passNow.push_back(wl);
+    return ++_wlSeen == _wlPerPass;
+}
+
+// Most of the weight update, early: when a training pass reaches its LAST weight layer every other weight layer has queued
+// its backward-data kernels (the only readers of its weights left in this step) on the main stream and its gradients on the
+// side stream, so one launch on the side stream -- ordered after both by the fork that follows -- can update all of them
+// while the main stream still computes the last layer's gradient.  The update after the join then covers that last layer
+// only (DeepID2: conv1, 784 of 3.2 M parameters; 12 -> 3 us at the very end of the step).  Same kernel and records as the
+// one-launch update, so the weights are bit-identical.  Not in data-parallel mode (the update follows the all-reduce).
+// MEASURED (DeepID2, MI355X): 0.282 -> 0.289 ms / step -- from fc6's gradient on the side stream is as busy as the main
+// stream, and 11 us more on it move the end of the step out further than the shorter final update pulls it in.  Opt-in
+// (MCN_EARLY_SGD=1) until the side stream carries less.
+void ConvNet::earlyUpdate() {
+    static const bool off = getenv("MCN_EARLY_SGD") == nullptr;  // opt-in, see above
+    if (off || dataParallel() || !_fusion || _sgdCount == 0 || _passOrder.size() < 2 || _passNow != _passOrder) return;
+    if (!_splitPlans && _capturing) return;  // (allocates and copies: not while a stream is being captured)
+    if (!_splitPlans) {
+        std::vector<::mcn_sgd_item> early, late;
+        for (auto& l : _layers) {
+            std::vector<Weights*> ws_;
+            l->collectWeights(ws_);
+            const bool isLast = l.get() == static_cast<Layer*>(_passOrder.back());
+            const bool visited = std::find(_passOrder.begin(), _passOrder.end(), dynamic_cast<WeightLayer*>(l.get())) != _passOrder.end();
+            for (Weights* w : ws_) {
+                ::mcn_sgd_item it;
+                if (w->planItem(false, it)) (visited && !isLast ? early : late).push_back(it);
+            }
+        }
+        _sgdEarlyCount = (int)early.size();
+        _sgdLateCount = (int)late.size();
+        if (_sgdEarlyCount > 0) {
+            const size_t pb = mcn_sgd_plan_bytes(_sgdEarlyCount);
+            _sgdEarly.ensure((pb + 3) / 4);
+            chk(mcn_sgd_plan_build(early.data(), _sgdEarlyCount, _sgdEarly.p, pb, &_sgdEarlyBlocks, _stream), "sgd plan (early)");
+        }
+        if (_sgdLateCount > 0) {
+            const size_t pb = mcn_sgd_plan_bytes(_sgdLateCount);
+            _sgdLate.ensure((pb + 3) / 4);
+            chk(mcn_sgd_plan_build(late.data(), _sgdLateCount, _sgdLate.p, pb, &_sgdLateBlocks, _stream), "sgd plan (late)");
+        }
+        _splitPlans = true;
+    }
+    if (_sgdEarlyCount == 0) return;
+    _earlyUpdateIssued = true;
+    deferSideWork([this] {
+        ProfScope ps(this, "net", "update (early)");
+        chk(mcn_sgd_update_planned(_sgdEarly.p, _sgdEarlyCount, _sgdEarlyBlocks, stream()), "sgd update (early)");
+    }, 0, true);
+}
 
 void ConvNet::deferSideWork(std::function<void()> fn, int units, bool hold) {
     if (!_gradStream || _profiling) {  // profiling times every operation on the main stream
@@ -1784,6 +1836,11 @@ void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
     for (auto& l : _layers) l->reset();
     _wlPerPass = _wlSeen;  // (the first pass learns how many weight layers a backward pass visits)
     _wlSeen = 0;
+    if (_passNow != _passOrder) {  // ... and in which order (earlyUpdate)
+        _passOrder = _passNow;
+        _splitPlans = false;
+    }
+    _passNow.clear();
     finishSideWork();
     if (_phases) profEnd();
     if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
@@ -1793,7 +1850,12 @@ void ConvNet::updateWeights() {  // convnet.cu:190-194
     if (dataParallel()) waitComm();
     if (_sgdCount > 0 && _fusion) {
         ProfScope ps(this, "net", "update");
-        chk(mcn_sgd_update_planned(_sgdPlan.p, _sgdCount, _sgdBlocks, _stream), "sgd update");
+        if (_earlyUpdateIssued) {  // this pass has updated everything but its last weight layer already
+            _earlyUpdateIssued = false;
+            if (_sgdLateCount > 0) chk(mcn_sgd_update_planned(_sgdLate.p, _sgdLateCount, _sgdLateBlocks, _stream), "sgd update (late)");
+        } else {
+            chk(mcn_sgd_update_planned(_sgdPlan.p, _sgdCount, _sgdBlocks, _stream), "sgd update");
+        }
         for (auto& l : _layers) l->weightsUpdated();
     } else {
         for (auto& l : _layers) l->updateWeights();
@@ -1819,7 +1881,6 @@ void ConvNet::captureStep(int miniIdx, StepGraph& g) {
         joinGradWork();
     } catch (...) {
         _capturing = false;
-    g_noHostWait = false;
         g_noHostWait = false;
         void* dead = nullptr;
         mcn_graph_end_capture(_stream, &dead, nullptr);

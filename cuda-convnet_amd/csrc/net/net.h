@@ -620,7 +620,8 @@ class ConvNet {
     // dependency costs ~12 us of host time, a launch ~3 -- and what is left when backward ends is split
     // between the side stream and the main stream.
     void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
-    bool lastWeightLayerOfPass();
+    bool lastWeightLayerOfPass(WeightLayer* wl);
+    void earlyUpdate();
     void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
     void finishSideWork();   // end of backward: place the remaining work, then join
     void joinGradWork();     // run whatever is still deferred on the main stream and wait for the side stream
@@ -706,6 +707,11 @@ class ConvNet {
     DBuf _costBuf;  // doubles, viewed as floats x2
     DBuf _sgdPlan;  // device records of the one-launch weight update
     int _sgdCount = 0, _sgdBlocks = 0;
+    // earlyUpdate: the same records split into (all but the last weight layer of a backward pass) / (the rest)
+    std::vector<WeightLayer*> _passOrder, _passNow;
+    DBuf _sgdEarly, _sgdLate;
+    int _sgdEarlyCount = 0, _sgdEarlyBlocks = 0, _sgdLateCount = 0, _sgdLateBlocks = 0;
+    bool _splitPlans = false, _earlyUpdateIssued = false;
     std::vector<double> _costHost;
     double _baseErr = 0;
 
