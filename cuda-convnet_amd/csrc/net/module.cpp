@@ -10,6 +10,7 @@
 //   startSteps(n, test=0, profile=0)     n minibatch steps cycling over the resident batch (finishBatch collects)
 //   getProfile()                         per-operation device time of the last profiled startSteps
 //   getCommLog() / getGradSegments()     the data-parallel exchange as it was issued, and the arena layout (tests)
+//   failNextBackwardAt(layerName)        one injected failure in the middle of the next backward pass (tests)
 // Differences from the reference that a caller can observe: errors raise RuntimeError
 // instead of exit(1)/assert; checkGradients returns its per-matrix results instead of
 // printing and calling exit(0); the GIL is released while a call blocks.
@@ -429,6 +430,16 @@ static PyObject* getGradSegments(PyObject*, PyObject*) {
     return Py_BuildValue("Nn", out, (Py_ssize_t)model->bucketFloats());
 }
 
+// failNextBackwardAt(layerName): the next backward pass throws when it reaches that weight layer -- after the layers above
+// it have queued their work on both streams (tests of the recovery after a failed step)
+static PyObject* failNextBackwardAt(PyObject*, PyObject* args) {
+    const char* name = nullptr;
+    if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
+    if (!needModel()) return nullptr;
+    model->failNextBackwardAt(name);
+    Py_RETURN_NONE;
+}
+
 static PyMethodDef methods[] = {
     {"initModel", initModel, METH_VARARGS, "initModel(layers, minibatchSize, deviceID)"},
     {"startBatch", startBatch, METH_VARARGS, "startBatch(data, test=0): asynchronous; data == [] uses the batch left by loadBatch"},
@@ -446,6 +457,7 @@ static PyMethodDef methods[] = {
     {"initDataParallel", initDataParallel, METH_VARARGS, "initDataParallel(rank, worldSize, uniqueId, force=0)"},
     {"getCommLog", getCommLog, METH_NOARGS, "getCommLog() -> [(kind, arenaOffset, count)] issued since the last call (data parallel)"},
     {"getGradSegments", getGradSegments, METH_NOARGS, "getGradSegments() -> ([(layer, begin, end)] in arena order, bucketFloats)"},
+    {"failNextBackwardAt", failNextBackwardAt, METH_VARARGS, "failNextBackwardAt(layerName): inject one failure into the next backward pass (tests)"},
     {"destroyModel", destroyModel, METH_NOARGS, "destroyModel()"},
     {nullptr, nullptr, 0, nullptr}};
 

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 #include "mi_convnet.h"
 
@@ -1407,9 +1408,62 @@ void ConvNet::run() {  // convnet.cu:147-156
             WorkResult r;
             r.type = WorkResult::ERROR;
             r.error = e.what();
+            try {
+                resetAfterError();
+            } catch (std::exception& e2) {
+                r.error += std::string(" (and while cleaning up: ") + e2.what() + ")";
+            }
             _results.enqueue(std::move(r));
         }
     }
+}
+
+// A work item threw in the middle of a pass: nothing of that pass may leak into the next one.  The submitting threads are
+// drained first (their closures hold pointers and the pass type of the failed pass), then every list, flag and counter of
+// the step schedule goes back to "between steps" and the device is drained.  The model is usable again afterwards -- except
+// a data-parallel replica: it has skipped collectives its peers are blocked in, so it refuses further work and the
+// launcher has to tear the group down.
+void ConvNet::resetAfterError() {
+    auto drain = [](Submitter& s) {
+        if (!s.running()) return;
+        try {
+            s.wait(s.pushed());
+        } catch (...) {  // (the error that is being reported, or one that followed from it)
+        }
+    };
+    drain(_side);
+    drain(_commSub);
+    _deferred.clear();
+    _deferredUnits = 0;
+    _late.clear();
+    _gradPending = false;
+    _exchangeWorkPending = false;
+    _earlyUpdateIssued = false;
+    _passNow.clear();
+    _wlSeen = 0;
+    {
+        std::lock_guard<std::mutex> lk(_commMutex);
+        _commPending = false;
+        _sentUpTo = 0;
+        for (Segment& sg : _segments) sg.ready = sg.byMain = false;
+    }
+    if (_capturing) {  // a capture must be ended before the stream can be used again
+        void* dead = nullptr;
+        mcn_graph_end_capture(_stream, &dead, nullptr);
+        if (dead) mcn_graph_destroy(dead);
+    }
+    _capturing = false;
+    g_noHostWait = false;
+    _profiling = _phases = false;
+    t_stream = 0;
+    for (auto& l : _layers) {
+        l->reset();
+        l->resetPassFlags();
+        l->weightsUpdated();  // numUpdates = 0: the next pass starts its gradients afresh (what the failed pass added to a
+                              // momentum matrix stays there: the caller decides whether to reload a checkpoint)
+    }
+    if (_dpOn) _failed = true;
+    mcn_device_sync();  // (a sticky device error shows up in the next call's status)
 }
 
 void ConvNet::initDevice() {  // convnet.cu:139-145
@@ -1592,6 +1646,14 @@ void ConvNet::waitSideSubmitted(long ticket) {
 }
 
 bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
+    if (_failArmed) {  // (set by bprop from failNextBackwardAt: test hook)
+        std::lock_guard<std::mutex> lk(_failMutex);
+        if (wl->name() == _failAt) {
+            _failAt.clear();
+            _failArmed = false;
+            throw NetError("injected failure at layer '" + wl->name() + "'");
+        }
+    }
     _passNow.push_back(wl);
     return ++_wlSeen == _wlPerPass;
 }
@@ -1804,6 +1866,7 @@ void ConvNet::joinGradWork() {
 }
 
 void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
+    if (_failed) throw NetError("this data-parallel replica failed in an earlier step and has left its group: destroy the model on every rank");
     joinGradWork();  // side-stream work of the previous minibatch (cost values in a test pass) reads buffers rewritten below
     for (auto& l : _layers) l->reset();
     for (DataLayer* d : _dataLayers) {
@@ -1827,6 +1890,10 @@ void ConvNet::fprop(int miniIdx, PassType pt) {  // convnet.cu:229-233
 }
 
 void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
+    {
+        std::lock_guard<std::mutex> lk(_failMutex);
+        _failArmed = !_failAt.empty();
+    }
     if (_phases) profBegin("phase.backward_data_chain");
     for (CostLayer* c : _costs) c->bprop(pt);
     if (_phases) {
@@ -2106,11 +2173,36 @@ double ConvNet::costValue() {
 // ---- gradient checking (convnet.cu:257-330) -----------------------------------------------------
 void ConvNet::checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) {
     if (dataParallel()) throw NetError("gradient checking runs on a single replica");
+    // The reference exits after a gradient check (convnet.cu:255); here the model stays usable, so the momentum state the
+    // PASS_GC backward overwrites -- it writes the raw gradient into `inc` of every matrix without a gradient buffer of
+    // its own (layer.cu:378, :554) -- is set aside first and put back afterwards.
+    std::vector<Weights*> all;
+    for (auto& l : _layers) l->collectWeights(all);
+    std::vector<std::pair<Weights*, std::unique_ptr<DBuf>>> saved;
+    for (Weights* w : all)
+        if (w->getGrad(false) == w->inc()) {
+            saved.emplace_back(w, std::unique_ptr<DBuf>(new DBuf()));
+            saved.back().second->ensure(w->size());
+            chk(mcn_d2d(saved.back().second->p, w->inc(), w->size() * 4, _stream), "d2d inc");
+        }
+    auto restore = [&] {
+        joinGradWork();
+        for (auto& sv : saved) chk(mcn_d2d(sv.first->inc(), sv.second->p, sv.first->size() * 4, _stream), "d2d inc");
+        for (auto& l : _layers) l->weightsUpdated();  // (numUpdates back to 0: the next training pass starts a fresh gradient)
+        sync();
+    };
+    try {
+        zeroCosts();
+        fprop(0, PASS_GC);
+        _baseErr = costValue();
+        bprop(PASS_GC);
+        for (auto& l : _layers) l->checkGradients(out, maxElems, central);
+    } catch (...) {
+        restore();
+        throw;
+    }
+    restore();
     zeroCosts();
-    fprop(0, PASS_GC);
-    _baseErr = costValue();
-    bprop(PASS_GC);
-    for (auto& l : _layers) l->checkGradients(out, maxElems, central);
 }
 
 }  // namespace mcn

@@ -110,6 +110,7 @@ class Layer {
     virtual void bprop(PassType pt);
     void bpropWith(float* v, PassType pt);
     void reset() { _rcvdF = _rcvdB = 0; _seeded = false; }
+    virtual void resetPassFlags() {}  // forget what a pass that did not finish left behind (ConvNet::resetAfterError)
     // A cost layer may deliver its gradient into this layer's gradient matrix ahead of the backward pass, on the side
     // stream (L2-SN: as soon as its cost statistics exist).  That counts as the first received gradient (everyone after it
     // accumulates), and whoever touches the matrix first during backward waits for the event.
@@ -245,6 +246,7 @@ class SoftmaxLayer : public Layer {
     DBuf part;               // stage-1 partials written by the producing FC layer's forward product
     size_t partBytes = 0;
     bool partReady = false;  // ... for the pass in flight
+    void resetPassFlags() override { partReady = false; _gradFused = false; }
     DBuf costState;          // tie counters + ticket of mcn_softmax_logreg_cost (zero between calls)
     size_t costStateBytes = 0;
    protected:
@@ -289,6 +291,7 @@ class PoolLayer : public Layer {
     // last of the pool's consumers to report: undoFusable = the windows tile the maps, this pool alone feeds the layer below
     bool undoFusable(int numCases, int channels, int outY, int outX) const;
     bool undoDoneAbove = false;  // ... for the pass in flight: bpropActs has nothing left to do
+    void resetPassFlags() override { undoDoneAbove = false; }
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
@@ -343,6 +346,7 @@ class LogregCostLayer : public CostLayer {
     float* logProbsBuf() { return _ownActs.p; }
     float* correctBuf() { return _aux.p; }
     bool costDoneBySoftmax = false;  // ... for the pass in flight
+    void resetPassFlags() override { costDoneBySoftmax = false; }
     void* softmaxState = nullptr;    // that softmax's counters (mcn_softmax_logreg_cost_finish)
     size_t softmaxStateBytes = 0;
    protected:
@@ -377,6 +381,9 @@ class L2SNCostLayer : public CostLayer {
     bool _readyOnExchange = false;
     int _extCount = 0;
     bool _earlyGrad = false;  // this pass already sent its gradient (forward, side stream)
+   public:
+    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; }
+   protected:
 };
 
 class Fisher2CostLayer : public CostLayer {  // layer.cu:1017-1047
@@ -621,6 +628,8 @@ class ConvNet {
     // between the side stream and the main stream.
     void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
     bool lastWeightLayerOfPass(WeightLayer* wl);
+    void failNextBackwardAt(const std::string& layer) { std::lock_guard<std::mutex> lk(_failMutex); _failAt = layer; }  // (any thread)
+    bool _failArmed = false;
     void earlyUpdate();
     void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
     void finishSideWork();   // end of backward: place the remaining work, then join
@@ -744,6 +753,10 @@ class ConvNet {
 
     // per-operation event timing (off on the normal path)
     bool _profiling = false, _phases = false;
+    std::string _failAt;   // failNextBackwardAt
+    std::mutex _failMutex;
+    bool _failed = false;  // a data-parallel replica that lost a step: its peers wait in a collective it will never join
+    void resetAfterError();
     struct ProfSpan { int label; void* e0; void* e1; size_t launches0; };
     std::vector<std::string> _profLabels;
     std::map<std::string, int> _profLabelIdx;

@@ -17,6 +17,8 @@ import time
 
 
 class Group:
+    MAX_MSG = 1 << 20  # control-plane messages are a unique id (128 bytes) or a scalar
+
     def __init__(self, rank=None, world=None, token=None, timeout=120.0):
         self.rank = int(os.environ.get('RANK', 0)) if rank is None else rank
         self.world = int(os.environ.get('WORLD_SIZE', 1)) if world is None else world
@@ -26,14 +28,20 @@ class Group:
         if self.world == 1:
             return
         token = token or '%d_%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
-        path = os.path.join(tempfile.gettempdir(), 'mcn_rdzv_%s.port' % token)
+        # a directory only this user can enter (another local user can neither pre-create the file nor read the port)
+        d = os.path.join(tempfile.gettempdir(), 'mcn_rdzv_%d' % os.getuid())
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError('%s is not a private directory of this user' % d)
+        path = os.path.join(d, '%s.port' % token)
         deadline = time.time() + timeout
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.bind(('127.0.0.1', 0))
             srv.listen(self.world)
             tmp = path + '.%d' % os.getpid()
-            with open(tmp, 'w') as f:
+            with os.fdopen(os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600), 'w') as f:
                 f.write('%d' % srv.getsockname()[1])
             os.replace(tmp, path)
             self._file = path
@@ -77,6 +85,8 @@ class Group:
 
     def _recv_msg(self, s):
         n = struct.unpack('<q', self._recv(s, 8))[0]
+        if not 0 <= n <= self.MAX_MSG:
+            raise ConnectionError('rendezvous message of %d bytes refused' % n)
         return self._recv(s, n)
 
     def broadcast(self, payload=None):

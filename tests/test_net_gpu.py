@@ -419,6 +419,34 @@ def test_gradient_check_small_net():
             assert rel < 0.02, (name, an, nn, rel)
 
 
+def test_training_after_a_gradient_check_is_unaffected():
+    """checkGradients leaves the model usable (the reference exits, convnet.cu:255): the PASS_GC backward writes raw gradients
+    into the momentum matrices, so they are set aside and restored -- a training step after a check must leave exactly the
+    weights the same step leaves without one."""
+    outs = []
+    for check in (False, True):
+        L, data = small_net(16, scale=8.0)
+        with Native(L, 16) as lib:
+            lib.startBatch(data, 0)   # one step first, so that the momentum matrices are not zero
+            lib.finishBatch()
+            if check:
+                lib.checkGradients(data, 10, 0)
+            lib.startBatch(data, 0)
+            cost = lib.finishBatch()
+            lib.syncWithHost()
+        outs.append((L, cost))
+    (La, ca), (Lb, cb) = outs
+    assert ca == cb
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for a, b in zip(la[key], lb[key]):
+                assert np.array_equal(a, b), (la['name'], key)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), (la['name'], key)
+
+
 def test_directional_gradcheck_through_the_boundary():
     from gradcheck import directional_check
     L, data = small_net(64)
@@ -439,6 +467,45 @@ def test_directional_gradcheck_through_the_boundary():
     assert len(res) == 9
     for name, num, anal, rel in res:
         assert rel < 0.02, (name, num, anal, rel)
+
+
+@pytest.mark.parametrize('name,layer', [('deepid2', 'conv2'), ('deepid2', 'fc5'), ('cifar10', 'conv1')])
+def test_a_failed_step_leaves_a_usable_model(name, layer):
+    """A step that throws in the middle of its backward pass (layers above have queued work on both streams and threads)
+    is reported as an exception, and nothing of it leaks into the next step: the model then behaves exactly like a fresh
+    model initialised with the state it holds -- same costs, same weights, bit for bit."""
+    dp, L = preset(name, 256)
+    data = dp.get_next_batch()[2]
+    with Native(L) as lib:
+        lib.startBatch(data, 0)
+        lib.finishBatch()
+        lib.failNextBackwardAt(layer)
+        lib.startBatch(data, 0)
+        with pytest.raises(RuntimeError, match='injected failure'):
+            lib.finishBatch()
+        lib.syncWithHost()              # the state after the failure, as the host sees it
+        L2 = copy.deepcopy(L)
+        lib.startBatch(data, 0)         # ... and on from there
+        cost_a = lib.finishBatch()
+        lib.startBatch(data, 1)
+        test_a = lib.finishBatch()
+        lib.syncWithHost()
+    with Native(L2) as lib:
+        lib.startBatch(data, 0)
+        cost_b = lib.finishBatch()
+        lib.startBatch(data, 1)
+        test_b = lib.finishBatch()
+        lib.syncWithHost()
+    assert cost_a == cost_b and test_a == test_b
+    assert all(np.isfinite(v).all() for v in cost_a[0].values())
+    for la, lb in zip(L, L2):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for a, b in zip(la[key], lb[key]):
+                assert np.array_equal(a, b), (la['name'], key)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), (la['name'], key)
 
 
 def test_errors_are_exceptions_not_exits():
