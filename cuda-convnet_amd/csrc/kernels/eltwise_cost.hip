@@ -109,10 +109,9 @@ __device__ __forceinline__ float block_sum256(float v, float* sh) {
     __syncthreads();
     return r;
 }
-__global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ mat, float* __restrict__ out, int cols, int chunks,
-                                                 int finalStage, float scaleThis, float scaleSum) {
-    __shared__ float sh[4];
-    const int row = blockIdx.x, chunk = blockIdx.y;
+// (row, chunk) of one matrix by one block
+__device__ __forceinline__ void row_sum_chunk(const float* __restrict__ mat, float* __restrict__ out, int cols, int chunks, int finalStage,
+                                              float scaleThis, float scaleSum, int row, int chunk, float* sh) {
     const int c0 = chunk * ROWSUM_CHUNK, c1 = min(cols, c0 + ROWSUM_CHUNK);
     const float* m = mat + (size_t)row * cols;
     float v = 0.f;
@@ -137,16 +136,53 @@ __global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ mat, 
         else out[(size_t)row * chunks + chunk] = s;
     }
 }
+__global__ __launch_bounds__(256) void k_row_sum(const float* __restrict__ mat, float* __restrict__ out, int cols, int chunks,
+                                                 int finalStage, float scaleThis, float scaleSum) {
+    __shared__ float sh[4];
+    row_sum_chunk(mat, out, cols, chunks, finalStage, scaleThis, scaleSum, blockIdx.x, blockIdx.y, sh);
+}
 // short rows (cols <= 256): one wave per row, 4 rows per block
-__global__ __launch_bounds__(256) void k_row_sum_short(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols,
-                                                       float scaleThis, float scaleSum) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void row_sum_short4(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols, float scaleThis,
+                                               float scaleSum, int block) {
+    const int row = block * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float* m = mat + (size_t)row * cols;
     float v = 0.f;
     for (int c = lane; c < cols; c += 64) v += m[c];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if (lane == 0) out[row] = (scaleThis != 0.f ? scaleThis * out[row] : 0.f) + scaleSum * v;
+}
+__global__ __launch_bounds__(256) void k_row_sum_short(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols,
+                                                       float scaleThis, float scaleSum) {
+    row_sum_short4(mat, out, rows, cols, scaleThis, scaleSum, blockIdx.x);
+}
+// The row sums of up to ROWSUM_MAX_ITEMS matrices in one launch (+ one more when a matrix has rows longer than a chunk): the
+// bias gradients of every layer of a backward pass are row sums over 0.1-19 MB each, one to two launches of 2-5 us per
+// layer in the reference's and this library's per-matrix form.  Every (matrix, row) is summed by the same code and in the
+// same order as in mcn_add_sum, so the results are bit-identical to per-matrix calls.
+#define ROWSUM_MAX_ITEMS 8
+struct RowSumSeg {
+    const float* mat;
+    float* out;
+    int rows, cols, chunks;  // chunks == 0: short rows (4 per block)
+    int finalStage;
+    int blockBase;           // first block of this segment
+    float scaleThis, scaleSum;
+};
+struct RowSumMulti {
+    RowSumSeg seg[ROWSUM_MAX_ITEMS];
+    int count;
+};
+__global__ __launch_bounds__(256) void k_row_sums_multi(const RowSumMulti p) {
+    __shared__ float sh[4];
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < ROWSUM_MAX_ITEMS; k++)
+        if (k < p.count && (int)blockIdx.x >= p.seg[k].blockBase) i = k;
+    const RowSumSeg& g = p.seg[i];
+    const int local = blockIdx.x - g.blockBase;
+    if (g.chunks == 0) row_sum_short4(g.mat, g.out, g.rows, g.cols, g.scaleThis, g.scaleSum, local);
+    else row_sum_chunk(g.mat, g.out, g.cols, g.chunks, g.finalStage, g.scaleThis, g.scaleSum, local / g.chunks, local % g.chunks, sh);
 }
 __global__ __launch_bounds__(256) void k_col_sum(const float* __restrict__ mat, float* __restrict__ out, int rows, int cols,
                                                  float scaleThis, float scaleSum) {
@@ -194,6 +230,52 @@ MCN_API int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int ax
             hipLaunchKernelGGL(k_row_sum, dim3(rows, 1), dim3(256), 0, s, (const float*)workspace, tgt, chunks, 1, 1, scaleThis, scaleSum);
     }
     return MCN_LAUNCH_CHECK("addSum");
+}
+
+MCN_API size_t mcn_add_sum_multi_workspace_bytes(const mcn_row_sum_item* items, int count) {
+    size_t need = 0;
+    for (int i = 0; i < count; i++) need += mcn_add_sum_workspace_bytes(items[i].rows, items[i].cols, 1);
+    return need;
+}
+MCN_API int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream) {
+    MCN_REQUIRE(items && count > 0 && count <= ROWSUM_MAX_ITEMS, "addSumMulti: 1..%d matrices per call", ROWSUM_MAX_ITEMS);
+    const size_t need = mcn_add_sum_multi_workspace_bytes(items, count);
+    if (need > 0 && (!workspace || workspaceBytes < need)) {
+        mcn_set_error("addSumMulti: workspace %zu < %zu bytes", workspaceBytes, need);
+        return MCN_EWORKSPACE;
+    }
+    RowSumMulti s1, s2;
+    s1.count = s2.count = 0;
+    int blocks1 = 0, blocks2 = 0;
+    float* part = (float*)workspace;
+    for (int i = 0; i < count; i++) {
+        const mcn_row_sum_item& it = items[i];
+        MCN_REQUIRE(it.tgt && it.mat && it.rows > 0 && it.cols > 0, "addSumMulti: bad matrix %d", i);
+        RowSumSeg& g = s1.seg[s1.count++];
+        g.mat = it.mat; g.rows = it.rows; g.cols = it.cols; g.blockBase = blocks1;
+        g.scaleThis = it.scaleThis; g.scaleSum = it.scaleSum;
+        if (it.cols <= 256) {  // as in mcn_add_sum
+            g.out = it.tgt; g.chunks = 0; g.finalStage = 1;
+            blocks1 += divup(it.rows, 4);
+        } else if (it.cols <= ROWSUM_CHUNK) {
+            g.out = it.tgt; g.chunks = 1; g.finalStage = 1;
+            blocks1 += it.rows;
+        } else {
+            const int chunks = divup(it.cols, ROWSUM_CHUNK);
+            g.out = part; g.chunks = chunks; g.finalStage = 0; g.scaleThis = 0.f; g.scaleSum = 1.f;
+            blocks1 += it.rows * chunks;
+            RowSumSeg& h = s2.seg[s2.count++];
+            h.mat = part; h.out = it.tgt; h.rows = it.rows; h.cols = chunks; h.blockBase = blocks2;
+            h.scaleThis = it.scaleThis; h.scaleSum = it.scaleSum; h.finalStage = 1;
+            if (chunks <= 256) { h.chunks = 0; blocks2 += divup(it.rows, 4); }
+            else { h.chunks = 1; blocks2 += it.rows; MCN_REQUIRE(chunks <= ROWSUM_CHUNK, "addSumMulti: row too long"); }
+            part += (size_t)it.rows * chunks;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_row_sums_multi, dim3(blocks1), dim3(256), 0, s, s1);
+    if (s2.count > 0) hipLaunchKernelGGL(k_row_sums_multi, dim3(blocks2), dim3(256), 0, s, s2);
+    return MCN_LAUNCH_CHECK("addSumMulti");
 }
 
 __global__ __launch_bounds__(256) void k_axpby(float* a, const float* b, size_t n, float sa, float sb) {

@@ -323,11 +323,18 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
     // last weight layer of the pass, which has nothing left to hide behind and is split over both streams
     const bool last = _net->lastWeightLayerOfPass(this);
     if (last && pt == PASS_TRAIN) _net->earlyUpdate();  // (queued ahead of this layer's own pieces, see there)
-    _net->deferSideWork([this, v, pt] {
+    _net->deferSideWork([this, v, pt, last] {
         if (_biases->eps() > 0) {
-            ProfScope ps(_net, _name, "bpropBiases");
-            bpropBiases(v, pt);
+            if (_net->biasBatching()) {  // a row sum like every other layer's: all of them in one launch at the end of the pass
+                int rows, cols;
+                biasSumShape(_net->numCases(), rows, cols);
+                _net->queueBiasSum(_biases->gradBuf(), v, rows, cols, gradScale(_biases->eps(), pt));
+            } else {
+                ProfScope ps(_net, _name, "bpropBiases");
+                bpropBiases(v, pt);
+            }
         }
+        if (last) _net->flushBiasSums();
     }, 1, true);
     _net->deferSideWork([this, v, pt] {
         for (int i = 0; i < (int)_weights.size(); i++) {
@@ -1441,6 +1448,8 @@ void ConvNet::resetAfterError() {
     _earlyUpdateIssued = false;
     _passNow.clear();
     _wlSeen = 0;
+    _biasBatch[0].clear();
+    _biasBatch[1].clear();
     {
         std::lock_guard<std::mutex> lk(_commMutex);
         _commPending = false;
@@ -1643,6 +1652,40 @@ void Submitter::wait(long ticket) {
 
 void ConvNet::waitSideSubmitted(long ticket) {
     if (ticket > 0) _side.wait(ticket);
+}
+
+// Bias gradients: row sums over 0.1-19 MB, one or two launches of 2-5 us per layer (eight per DeepID2 step, ~30 us of the
+// side stream).  A single-GPU pass queues them and the last weight layer's bias piece (side stream) issues all of them as
+// one mcn_add_sum_multi (two launches); what a pass leaves queued (its first pass, before the number of weight layers is
+// known) is issued by bprop() itself.  Data parallel: per layer as before, the buckets of the exchange need them early.
+bool ConvNet::biasBatching() const {
+    static const bool off = getenv("MCN_NO_BIAS_BATCH") != nullptr;
+    return !off && _fusion && !_dpOn;
+}
+void ConvNet::queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum) {
+    _biasBatch[t_stream == 1 ? 1 : 0].push_back({tgt, mat, rows, cols, scaleSum});
+}
+void ConvNet::flushBiasSums(int which) {
+    std::vector<BiasSum>& b = _biasBatch[which >= 0 ? which : (t_stream == 1 ? 1 : 0)];
+    if (b.empty()) return;
+    ProfScope ps(this, "net", "biasGrads");
+    for (size_t i = 0; i < b.size(); i += 8) {
+        const int cnt = (int)std::min<size_t>(8, b.size() - i);
+        ::mcn_row_sum_item items[8];
+        for (int k = 0; k < cnt; k++) {
+            const BiasSum& q = b[i + k];
+            items[k].tgt = q.tgt; items[k].mat = q.mat; items[k].rows = q.rows; items[k].cols = q.cols;
+            items[k].scaleThis = 0.f; items[k].scaleSum = q.scaleSum;
+        }
+        if (mcn_add_sum_multi_workspace_bytes(items, cnt) <= workspaceBytes()) {
+            chk(mcn_add_sum_multi(items, cnt, workspace(), workspaceBytes(), stream()), "bias gradients");
+        } else {
+            for (int k = 0; k < cnt; k++)
+                chk(mcn_add_sum(items[k].tgt, items[k].mat, items[k].rows, items[k].cols, 1, 0.f, items[k].scaleSum, workspace(), workspaceBytes(),
+                                stream()), "bias gradient");
+        }
+    }
+    b.clear();
 }
 
 bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
@@ -1909,6 +1952,8 @@ void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
     }
     _passNow.clear();
     finishSideWork();
+    flushBiasSums(1);  // (after the join: whatever the pass left queued, on the main stream)
+    flushBiasSums(0);
     if (_phases) profEnd();
     if (dataParallel() && pt == PASS_TRAIN) flushBuckets(true);
 }

@@ -198,6 +198,7 @@ class WeightLayer : public Layer {
    protected:
     void bpropCommon(float* v, PassType pt) override;
     virtual void bpropBiases(float* v, PassType pt) = 0;
+    virtual void biasSumShape(int numCases, int& rows, int& cols) const = 0;  // bpropBiases as a row sum of v (rows x cols)
     virtual void bpropWeights(float* v, int inpIdx, PassType pt) = 0;
     float gradScale(float eps, PassType pt) const;  // eps / (numCases * worldSize), 1 for PASS_GC
     std::vector<std::unique_ptr<Weights>> _weights;
@@ -219,6 +220,7 @@ class FCLayer : public WeightLayer {
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
     void bpropBiases(float* v, PassType) override;
+    void biasSumShape(int numCases, int& rows, int& cols) const override { rows = _outputs; cols = numCases; }
     void bpropWeights(float* v, int, PassType) override;
     bool _fwdAllDone = false;
     std::vector<char> _bwdDone;
@@ -232,6 +234,10 @@ class LocalLayer : public WeightLayer {
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
     void bpropBiases(float* v, PassType) override;
+    void biasSumShape(int numCases, int& rows, int& cols) const override {
+        if (_conv && _sharedBiases) { rows = _filters; cols = _modules * numCases; }
+        else { rows = _filters * _modules; cols = numCases; }
+    }
     void bpropWeights(float* v, int, PassType) override;
     bool _conv;
     std::vector<long> _padding, _stride, _filterSize, _channels, _imgSizeY, _imgSizeX, _groups, _filterChannels;
@@ -628,6 +634,10 @@ class ConvNet {
     // between the side stream and the main stream.
     void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
     bool lastWeightLayerOfPass(WeightLayer* wl);
+    // bias gradients of a backward pass, handed to ONE mcn_add_sum_multi by the last weight layer's bias piece (single GPU)
+    bool biasBatching() const;
+    void queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum);
+    void flushBiasSums(int which = -1);  // -1: the calling thread's batch
     void failNextBackwardAt(const std::string& layer) { std::lock_guard<std::mutex> lk(_failMutex); _failAt = layer; }  // (any thread)
     bool _failArmed = false;
     void earlyUpdate();
@@ -753,6 +763,8 @@ class ConvNet {
 
     // per-operation event timing (off on the normal path)
     bool _profiling = false, _phases = false;
+    struct BiasSum { float* tgt; const float* mat; int rows, cols; float scaleSum; };
+    std::vector<BiasSum> _biasBatch[2];  // queued by closures on the main [0] / side [1] submitting thread
     std::string _failAt;   // failNextBackwardAt
     std::mutex _failMutex;
     bool _failed = false;  // a data-parallel replica that lost a step: its peers wait in a collective it will never join

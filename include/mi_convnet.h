@@ -277,6 +277,18 @@ int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow,
 size_t mcn_add_sum_workspace_bytes(int rows, int cols, int axis);
 int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int axis, float scaleThis, float scaleSum,
                 void* workspace, size_t workspaceBytes, void* stream);
+/* The same row sums (axis 1) for up to 8 matrices in one launch, plus one more launch when a matrix has rows longer than
+ * 8192 columns: tgt_i = scaleThis_i*tgt_i + scaleSum_i*rowsums(mat_i), bit-identical to one mcn_add_sum per matrix.  The
+ * reference issues an addSum per layer for its bias gradients (layer.cu:464-474, :545-549, FCLayer::bpropBiases); a
+ * backward pass can hand all of them over at once. */
+typedef struct mcn_row_sum_item {
+    float* tgt;
+    const float* mat;
+    int rows, cols;
+    float scaleThis, scaleSum;
+} mcn_row_sum_item;
+size_t mcn_add_sum_multi_workspace_bytes(const mcn_row_sum_item* items, int count);
+int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream);
 /* NVMatrix::add (nvmatrix.cuh eltwise WeightedAdd): a = sa*a + sb*b */
 int mcn_axpby(float* a, const float* b, size_t n, float sa, float sb, void* stream);
 /* NVMatrix::scale / copy with scale: out = s*in */

@@ -957,3 +957,38 @@ def test_img_acts_through_max_pool_and_neuron(name, sT, N):
         call('mcn_img_acts_max_undo', dev(hid), dev(W), None, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 1 if conv else 0, 0.0, 1.0,
              dev(acts), dev(pooled), d_got, 1, 0.0, 0.0, None)
         close(d_got.numpy(), wu, what='imgActs + max undo + relu grad')
+
+
+def test_add_sum_multi_equals_per_matrix_add_sum():
+    """mcn_add_sum_multi: the bias-gradient row sums of a whole DeepID2 backward pass (fc6, fc5, local4, local3, conv2, conv1
+    shapes: short rows, one-chunk rows, many-chunk rows) in two launches == one mcn_add_sum per matrix, bit for bit."""
+    class Item(C.Structure):
+        _fields_ = [('tgt', C.c_void_p), ('mat', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int), ('scaleThis', C.c_float),
+                    ('scaleSum', C.c_float)]
+    rng = np.random.default_rng(46)
+    N = 128
+    shapes = [(10575, N, 0.0), (160, N, 0.0), (64 * 16, N, 0.5), (48 * 100, N, 0.0), (32, 576 * N, 0.0), (16, 2704 * N, 0.9), (5, 1000, 0.0),
+              (3, 8192 * 3 + 4, 0.0)]
+    items = (Item * len(shapes))()
+    keep, want = [], []
+    for i, (rows, cols, sT) in enumerate(shapes):
+        mat, t0 = mk(rng, rows, cols), mk(rng, rows)
+        d_mat, d_t, d_w = dev(mat), dev(t0), dev(t0)
+        nb = ws_bytes('mcn_add_sum_workspace_bytes', rows, cols, 1)
+        ws = capi.workspace(nb)
+        call('mcn_add_sum', d_w, d_mat, rows, cols, 1, sT, 0.01, ws, nb, None)
+        want.append(d_w.numpy().copy())
+        keep.append((d_mat, d_t, mat, t0, sT))
+        items[i] = Item(d_t.ptr, d_mat.ptr, rows, cols, sT, 0.01)
+    L = capi.lib()
+    nb = int(L.raw('mcn_add_sum_multi_workspace_bytes')(C.cast(items, C.c_void_p), len(shapes)))
+    assert nb == sum(ws_bytes('mcn_add_sum_workspace_bytes', r, c, 1) for r, c, _ in shapes)
+    ws = capi.workspace(nb)
+    L.call('mcn_add_sum_multi', C.cast(items, C.c_void_p), len(shapes), ws, nb, None)
+    for (d_mat, d_t, mat, t0, sT), w, shp in zip(keep, want, shapes):
+        got = d_t.numpy()
+        assert np.array_equal(got, w), shp
+        ref = sT * t0.astype(np.float64) + 0.01 * mat.astype(np.float64).sum(1)
+        close(got, ref.astype(np.float32), rtol=2e-5, what='row sums %r' % (shp,))
+    with pytest.raises(Exception):
+        L.call('mcn_add_sum_multi', C.cast(items, C.c_void_p), 9, ws, nb, None)
