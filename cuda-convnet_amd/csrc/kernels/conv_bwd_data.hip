@@ -254,6 +254,10 @@ static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipeli
                 grid.y = divup(p.imgY * p.imgX, 4 / ksplit);                                                              \
                 if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
                 else hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
+            } else if constexpr (CV == 2 && NQ == 1) {                                                                    \
+                grid.y = divup(p.imgY * p.imgX, 4 / ksplit);                                                              \
+                if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
+                else hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
             }                                                                                                             \
         } else hipLaunchKernelGGL((k_img_acts<CV, NQ, true, 1, 1, UN>), grid, dim3(256), 0, s, p);                        \
     } while (0)
@@ -264,6 +268,12 @@ static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipeli
     }
     if (vecn && pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U>), grid, dim3(256), 0, s, p);
     else if (vecn && ksplit) {
+        if constexpr (CV == 2 && NQ == 1) {
+            grid.y = divup(p.imgY * p.imgX, 4 / ksplit);
+            // (two 16-channel tiles per wave halve the re-reads of the gradient rows; 4 steps per register set: conv2+ 92 -> 85 us)
+            if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<2, 1, true, 4, 4>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 2>), grid, dim3(256), 0, s, p);
+        }
         if constexpr (CV == 1 && NQ == 1) {
             grid.y = divup(p.imgY * p.imgX, 4 / ksplit);  // 4 / KS pixels per block
             // prefetch depth of the pixel-split form: 2 steps per register set (in the DeepID2 step 5 us faster than 1 -- local3
@@ -346,10 +356,19 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     // the prefetched form where both apply)
     int ksplit = vecn && CV == 1 && NQ == 1 && (F / groups / 16) >= 2 && waves(CV, NQ) < 2048 && divup(imgPixels, 2) <= 65535 ? 2 : 0;
     if (ksplit && (F / groups / 16) >= 4 && waves(CV, NQ) < 1024 && imgPixels <= 65535) ksplit = 4;  // (local4: 7.0 -> 6.4 us)
+    // wide layers (an even number of 16-channel tiles, >= 64 filters per group) with few pixels x images: four waves per pixel
+    // with TWO channel tiles each instead of one wave per (pixel, 32-64 channels) walking all its steps alone
+    // (DeepID2+ conv2: 120 -> 85 us, local3: 116 -> 70 us; MCN_IA_WIDE=0 restores the old choice)
+    static const bool wideSplit = !(getenv("MCN_IA_WIDE") && atoi(getenv("MCN_IA_WIDE")) == 0);
+    if (wideSplit && vecn && ct16 % 2 == 0 && (F / groups / 16) >= 4 && imgPixels <= 65535 &&
+        (long)divup(N, 64) * imgPixels * groups * (ct16 / 2) < 2048) {
+        CV = 2; NQ = 1; ksplit = 4;
+        grid = dim3(divup(N, 64), divup(imgPixels, 4), groups * (ct16 / 2));
+    }
     switch (CV) {
         case 4: launch_bd1<4>(p, NQ, grid, vecn, pipelined, 0, s); break;
         case 3: launch_bd1<3>(p, NQ, grid, vecn, pipelined, 0, s); break;
-        case 2: launch_bd1<2>(p, NQ, grid, vecn, pipelined, 0, s); break;
+        case 2: launch_bd1<2>(p, NQ, grid, vecn, pipelined && !ksplit, ksplit, s); break;
         default: launch_bd1<1>(p, NQ, grid, vecn, pipelined && !ksplit, ksplit, s); break;
     }
     return MCN_LAUNCH_CHECK("imgActs");

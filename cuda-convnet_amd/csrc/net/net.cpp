@@ -216,7 +216,17 @@ void Layer::fprop(const std::vector<float*>& inputs, PassType pt) {  // layer.cu
             ProfScope ps(_net, _name, "fprop", i);
             fpropActs(i, (_actsTarget >= 0 || i > 0) ? 1.f : 0.f, pt);
         }
-    for (Layer* l : _next) l->fpropFromPrev(pt);
+    // cost layers first: their work is forked to the side stream, and a fork covers everything the main stream holds at
+    // that point -- after fc6's product had been queued, the L2-SN cost behind fc5 started a whole fc6 forward later
+    static const bool costFirst = getenv("MCN_NO_COST_FIRST") == nullptr;
+    if (costFirst && _next.size() > 1) {
+        for (Layer* l : _next)
+            if (l->type().compare(0, 5, "cost.") == 0) l->fpropFromPrev(pt);
+        for (Layer* l : _next)
+            if (l->type().compare(0, 5, "cost.") != 0) l->fpropFromPrev(pt);
+    } else {
+        for (Layer* l : _next) l->fpropFromPrev(pt);
+    }
 }
 
 void Layer::bprop(PassType pt) {  // layer.cu:116-121
