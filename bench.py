@@ -47,7 +47,12 @@ def op_work(layers, label, N):
         nConv = sum(w.size for x in layers if x['type'] == 'conv' for w in x['weights'])
         nB = sum(x['biases'].size for x in layers if 'weights' in x)
         return 3.0 * nW, 4.0 * (4 * nW + nConv + 5 * nB), 'hbm'
-    l = next(x for x in layers if x['name'] == lname)
+    if lname == 'net' and op == 'biasGrads':  # the row sums of every layer's gradient matrix in one call (mcn_add_sum_multi)
+        n = sum(N * x['outputs'] for x in layers if 'weights' in x)
+        return n, 4.0 * n, 'hbm'
+    l = next((x for x in layers if x['name'] == lname), None)
+    if l is None:  # an operation of the net itself that has no entry above
+        return 0.0, 0.0, 'hbm'
     t = l['type']
     if t in ('conv', 'local'):
         M, F = l['modules'], l['filters']

@@ -11,6 +11,7 @@
 // 4 consecutive filters of its weight row with one 16-byte load and uses
 // component s in k-step s; the matching B rows are f = f16 + 4*kk + s.
 // No atomics, no LDS transposes; results are deterministic.
+#include <cstring>
 #include "common.h"
 
 struct BwdDataParams {
@@ -300,6 +301,22 @@ static void launch_bd1(const BwdDataParams& p, int nq, dim3 grid, bool vecn, boo
     else launch_bd2<CV, 1>(p, grid, vecn, pipelined, ksplit, s);
 }
 
+// Per calling thread (mcn_set_thread_option "img_acts_wide"): 4 (default) = the four-waves-per-pixel form for wide layers, the
+// fastest launch on an otherwise idle GPU; 0 = one wave per pixel.  A caller that keeps a second stream busy with weight
+// gradients sets 0: the wide form fills every wave slot and the other queue's kernels wait (DeepID2+ step: 0.905 ms with
+// the wide form on the backward-data chain, 0.817 ms with the narrow one, although each launch alone is 30 % slower).
+static thread_local int t_imgActsWide = 4;
+MCN_API int mcn_set_thread_option(const char* name, int value) {
+    MCN_REQUIRE(name, "setThreadOption: null name");
+    if (strcmp(name, "img_acts_wide") == 0) {
+        MCN_REQUIRE(value == 0 || value == 2 || value == 4, "setThreadOption: img_acts_wide is 0, 2 or 4");
+        t_imgActsWide = value;
+        return MCN_OK;
+    }
+    mcn_set_error("setThreadOption: unknown option '%s'", name);
+    return MCN_EINVAL;
+}
+
 struct UndoArgs {
     const float* acts;
     const float* maxActs;
@@ -359,10 +376,12 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     // wide layers (an even number of 16-channel tiles, >= 64 filters per group) with few pixels x images: four waves per pixel
     // with TWO channel tiles each instead of one wave per (pixel, 32-64 channels) walking all its steps alone
     // (DeepID2+ conv2: 120 -> 85 us, local3: 116 -> 70 us; MCN_IA_WIDE=0 restores the old choice)
-    static const bool wideSplit = !(getenv("MCN_IA_WIDE") && atoi(getenv("MCN_IA_WIDE")) == 0);
+    static const int wideEnv = getenv("MCN_IA_WIDE") ? atoi(getenv("MCN_IA_WIDE")) : -1;
+    const int wideKs = wideEnv >= 0 ? wideEnv : t_imgActsWide;
+    const bool wideSplit = wideKs != 0;
     if (wideSplit && vecn && ct16 % 2 == 0 && (F / groups / 16) >= 4 && imgPixels <= 65535 &&
         (long)divup(N, 64) * imgPixels * groups * (ct16 / 2) < 2048) {
-        CV = 2; NQ = 1; ksplit = 4;
+        CV = 2; NQ = 1; ksplit = wideKs == 2 ? 2 : 4;
         grid = dim3(divup(N, 64), divup(imgPixels, 4), groups * (ct16 / 2));
     }
     switch (CV) {

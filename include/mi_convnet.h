@@ -142,6 +142,12 @@ int mcn_img_acts_max_undo(const float* hidActs, const float* filters, const floa
                           const float* poolInput, const float* poolOutput, float* undoTarget, int neuron, float neuronA,
                           float neuronB, void* stream);
 
+/* Tuning switches of the calling thread (no counterpart in the reference).  "img_acts_wide": 4 (default) | 2 | 0 -- waves per
+ * input pixel in the backward-data product of wide layers (>= 64 filters per group, an even number of 16-channel tiles,
+ * few pixels x images).  4 is the fastest launch on an idle GPU (DeepID2+ conv2 120 -> 85 us); a caller that runs weight
+ * gradients on a second stream at the same time sets 0 (see conv_bwd_data.hip). */
+int mcn_set_thread_option(const char* name, int value);
+
 /* convWeightActs (cudaconv2.cuh:67-70, weight_acts.cu:955-964): targets
  * ((modules/partialSum)*filterChannels*filterPixels, numFilters); partialSum <= 0 means all modules.
  * localWeightActs (cudaconv2.cuh:76-78, weight_acts.cu:966-976): targets
