@@ -35,7 +35,7 @@ static bool g_noHostWait = false;  // (stream capture in progress: events cannot
 int timedStreamWait(void* s, void* e) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc = MCN_OK;
-    if (!g_noHostWait && t_stream <= 1 && ((g_hostWaitMask >> t_stream) & 1)) {
+    if (!g_noHostWait && t_stream <= 2 && ((g_hostWaitMask >> t_stream) & 1)) {
         int q;
         while ((q = mcn_event_query(e)) == 0) {}
         if (q < 0) rc = q;
@@ -1827,7 +1827,7 @@ long ConvNet::forkExchangeWork(std::function<void()> fn) {
     _exchangeWorkPending = true;
     return _commSub.push([this, forkEvent, fn] {
         t_stream = 2;
-        chk(mcn_stream_wait_event(_commStream, forkEvent), "wait event");
+        chk(timedStreamWait(_commStream, forkEvent), "wait event");
         fn();
     });
 }
@@ -2100,8 +2100,8 @@ void ConvNet::flushBuckets(bool force) {
     float* buf = _gradArena.p + _sentUpTo;
     const size_t count = end - _sentUpTo;
     _commSub.push([this, evMain, evSide, buf, count] {
-        if (evMain) chk(mcn_stream_wait_event(_commStream, evMain), "wait event");
-        if (evSide) chk(mcn_stream_wait_event(_commStream, evSide), "wait event");
+        if (evMain) chk(timedStreamWait(_commStream, evMain), "wait event");
+        if (evSide) chk(timedStreamWait(_commStream, evSide), "wait event");
         const auto t0 = std::chrono::steady_clock::now();
         chk(mcn_allreduce_sum(_comm, buf, count, _commStream), "all-reduce");
         logComm(0, (size_t)(buf - _gradArena.p), count);

@@ -46,6 +46,9 @@ OPS = {
     'conv1.bpropWeights[0]': ('wa1', ['void k_conv_wgrad_strip<3, 1>', 'k_reduce_chunks'], CONV1[0] + CONV1[1] + CONV1[2],
                               'k_reduce_chunks averaged over conv1 and conv1+'),
     'conv2.bpropWeights[0]': ('wa2', ['void k_weight_acts<2, 2, 2>', 'k_reduce_chunks'], CONV2[0] + CONV2[1] + CONV2[2], 'k_reduce_chunks averaged over conv2 and conv2+'),
+    # not an operation of the DeepID2 step: the DeepID2+ conv2 backward-data product alone (tools/kbench.py conv2+), wide form
+    'kbench conv2+ imgActs': ('iaw', ['void k_img_acts<2, 1, true, 4, 4, 0>'], sum(conv_bytes(26, 26, 32, 128, 3, 24, 24, True)),
+                              'four waves per pixel, two channel tiles each: every pixel re-reads the gradient rows of the <= 9 modules covering it (through L2)'),
     'local3.fprop[0]': ('fa', ['void k_filter_acts<3, 1, 9, true, true, 8>'], sum(LOCAL3), ''),
 }
 
