@@ -102,6 +102,18 @@ def main():
         flops, nbytes = 2.0 * N * I * O_, 4.0 * (O_ * I + I * N + O_ * N)
         report(name + ' fwd (NN)', (lambda: call('mcn_gemm_bias_neuron', W, X, b, Y, O_, N, I, 0.0, 0, 0.0, 0.0, ws, ws.nbytes, None)), flops, nbytes)
         report(name + ' bwd-data (TN)', (lambda: call('mcn_gemm', W, dY, dX, I, N, O_, 1, 0, 1.0, 0.0, ws, ws.nbytes, None)), flops, nbytes)
+        if O_ >= 512 and N % 4 == 0:  # the classifier under a softmax + logreg cost: stage 1 in the product, stage 2 + gradient + cost counts
+            nb = ws_bytes('mcn_softmax_workspace_bytes', O_, N)
+            part = capi.workspace(nb)
+            sb = ws_bytes('mcn_softmax_logreg_cost_state_bytes', N)
+            state = capi.workspace(sb)
+            call('mcn_memset', state, 0, sb, None)
+            labels = dev(rng.integers(0, O_, (1, N)).astype(np.float32))
+            probs, grad, lp, cp = dev_empty((O_, N)), dev_empty((O_, N)), dev_empty((1, N)), dev_empty((1, N))
+            from kutil import dev_double
+            cost = dev_double(2)
+            call('mcn_gemm_bias_neuron_softmax_part', W, X, b, Y, O_, N, I, 0, 0.0, 0.0, part, nb, None)
+            report(name + ' softmax+grad+cost', (lambda: call('mcn_softmax_logreg_cost', Y, probs, labels, grad, 1.0, O_, N, part, nb, ws, ws.nbytes, lp, cp, cost, state, sb, 1, None)), 4.0 * N * O_, 4.0 * 3 * N * O_)
         report(name + ' bwd-weights (NT)', (lambda: call('mcn_gemm', dY, X, dW, O_, I, N, 0, 1, 0.001, 0.9, ws, ws.nbytes, None)), flops, nbytes)
 
 
