@@ -733,6 +733,112 @@ int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi
     return MCN_LAUNCH_CHECK("fcBpropActsMulti");
 }
 
+// ---- backward-weights: dW_i[M x I_i] = beta_i dW_i + alpha_i dY X_i^T  (reduction over the cases, short: 128).  One WAVE per
+// 32 x 32 tile of one dW_i: lane (j, kk) reads 4 consecutive cases of dY rows m0 + j / m0 + 16 + j and of X_i rows
+// i0 + 2j / i0 + 2j + 1 (column j of tile t <-> input i0 + 2j + t: a lane stores two consecutive inputs of a row), every
+// case step of a batch requested up front, the momentum tile (beta_i dW_i) before them; no LDS, no barrier.
+// FcMultiParams: B[i] = X_i, C[i] = dW_i, K[i] = I_i, steps[i] = 32-column tiles of input i, dY, M, N = cases, na[i] = alpha_i.
+template <int U>
+__global__ __launch_bounds__(64) void k_fc_wgrad_multi(const FcMultiParams p) {
+    const int lane = threadIdx.x, kk = lane >> 4, j = lane & 15;
+    int seg = 0, tile = blockIdx.y;
+    while (tile >= p.steps[seg]) { tile -= p.steps[seg]; seg++; }
+    const int I = p.K[seg], i0 = tile * 32, m0 = blockIdx.x * 32;
+    const float* X = p.B[seg];
+    float* C = p.C[seg];
+    const float alpha = p.na[seg], beta = p.beta[seg];
+    const bool iin = i0 + 2 * j < I;  // I even
+    const float* a0p = p.dY + (size_t)min(m0 + j, p.M - 1) * p.N + 4 * kk;
+    const float* a1p = p.dY + (size_t)min(m0 + 16 + j, p.M - 1) * p.N + 4 * kk;
+    const float* b0p = X + (size_t)min(i0 + 2 * j, I - 1) * p.N + 4 * kk;
+    const float* b1p = X + (size_t)min(i0 + 2 * j + 1, I - 1) * p.N + 4 * kk;
+    f32x2 cold[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = min(m0 + 16 * u + 4 * kk + r, p.M - 1);
+            cold[u][r] = (beta != 0.f && iin) ? *reinterpret_cast<const f32x2*>(C + (size_t)m * I + i0 + 2 * j) : (f32x2){0.f, 0.f};
+        }
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) acc[t] = F4ZERO;
+    const int steps = (p.N + 15) / 16;  // N % 4 == 0
+    for (int s0 = 0; s0 < steps; s0 += U) {
+        f32x4 a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int k = 16 * (s0 + u) + 4 * kk;
+            const bool kin = s0 + u < steps && k < p.N;
+            a0[u] = kin ? ldg4(a0p + 16 * (s0 + u)) : F4ZERO;
+            a1[u] = kin ? ldg4(a1p + 16 * (s0 + u)) : F4ZERO;
+            b0[u] = kin ? ldg4(b0p + 16 * (s0 + u)) : F4ZERO;
+            b1[u] = kin ? ldg4(b1p + 16 * (s0 + u)) : F4ZERO;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                acc[0] = mfma16(a0[u][e], b0[u][e], acc[0]);
+                acc[1] = mfma16(a0[u][e], b1[u][e], acc[1]);
+                acc[2] = mfma16(a1[u][e], b0[u][e], acc[2]);
+                acc[3] = mfma16(a1[u][e], b1[u][e], acc[3]);
+            }
+    }
+    if (!iin) return;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = m0 + 16 * u + 4 * kk + r;
+            if (m >= p.M) continue;
+            f32x2 o = alpha * (f32x2){acc[2 * u][r], acc[2 * u + 1][r]};
+            if (beta != 0.f) o += beta * cold[u][r];
+            *reinterpret_cast<f32x2*>(C + (size_t)m * I + i0 + 2 * j) = o;
+        }
+}
+
+bool fc_wgrad_multi_usable(const float* dY, const float* const* X, float* const* dW, const int* Ii, int count, int M, int N) {
+    if (count < 1 || count > FCM_MAXSEG || M < 1 || N < 4 || N % 4 != 0 || !al16(dY)) return false;
+    long tiles = 0;
+    for (int i = 0; i < count; i++) {
+        if (Ii[i] < 2 || Ii[i] % 2 != 0 || !al16(X[i]) || !dW[i] || ((uintptr_t)dW[i] % 8) != 0) return false;
+        tiles += divup(Ii[i], 32);
+    }
+    return tiles <= 65535 && divup(M, 32) <= 65535;
+}
+
+int fc_wgrad_multi_launch(const float* dY, const float* const* X, float* const* dW, const int* Ii, const float* alpha, const float* beta,
+                          int count, int M, int N, hipStream_t s) {
+    FcMultiParams p = {};
+    p.nseg = count;
+    int tiles = 0;
+    for (int i = 0; i < count; i++) {
+        p.B[i] = X[i]; p.C[i] = dW[i]; p.K[i] = Ii[i]; p.steps[i] = divup(Ii[i], 32); p.beta[i] = beta[i]; p.na[i] = alpha[i];
+        tiles += p.steps[i];
+    }
+    for (int i = count; i < FCM_MAXSEG; i++) p.steps[i] = 1 << 30;
+    p.dY = dY; p.M = M; p.N = N;
+    dim3 grid(divup(M, 32), tiles);
+    hipLaunchKernelGGL((k_fc_wgrad_multi<8>), grid, dim3(64), 0, s, p);
+    return MCN_LAUNCH_CHECK("fcBpropWeightsMulti");
+}
+
+MCN_API int mcn_fc_bprop_weights_multi_supported(const float* actsGrad, const float* const* inputs, float* const* targets,
+                                                 const int* numInputs, int count, int numOutputs, int numCases) {
+    return (actsGrad && inputs && targets && numInputs &&
+            fc_wgrad_multi_usable(actsGrad, inputs, targets, numInputs, count, numOutputs, numCases)) ? 1 : 0;
+}
+MCN_API int mcn_fc_bprop_weights_multi(const float* actsGrad, const float* const* inputs, float* const* targets, const int* numInputs,
+                                       const float* scaleOutput, const float* scaleTargets, int count, int numOutputs, int numCases,
+                                       void* stream) {
+    MCN_REQUIRE(actsGrad && inputs && targets && numInputs && scaleOutput && scaleTargets, "fcBpropWeightsMulti: null pointer");
+    MCN_REQUIRE(fc_wgrad_multi_usable(actsGrad, inputs, targets, numInputs, count, numOutputs, numCases),
+                "fcBpropWeightsMulti: unsupported shape (even input sizes, case count a multiple of 4, 16-byte aligned operands, at most %d inputs)",
+                FCM_MAXSEG);
+    return fc_wgrad_multi_launch(actsGrad, inputs, targets, numInputs, scaleOutput, scaleTargets, count, numOutputs, numCases,
+                                 (hipStream_t)stream);
+}
 MCN_API int mcn_fc_fprop_multi_supported(const float* const* weights, const float* const* inputs, const int* numInputs, int count,
                                          const float* acts, int numOutputs, int numCases) {
     return (weights && inputs && numInputs && fc_fprop_multi_usable(weights, inputs, numInputs, count, acts, numOutputs, numCases)) ? 1 : 0;

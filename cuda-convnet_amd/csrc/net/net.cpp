@@ -508,8 +508,39 @@ void FCLayer::bpropBiases(float* v, PassType pt) {
 
 void FCLayer::bpropWeights(float* v, int i, PassType pt) {
     const int n = _net->numCases(), I = _prev[i]->outputs();
-    Weights& w = *_weights[i];
     const bool dp = _net->dataParallel();
+    // several inputs (fc5): the gradients of all weight matrices in one launch, issued with the first input
+    static const bool noMulti = getenv("MCN_NO_FC_MULTI") != nullptr || getenv("MCN_NO_FC_WGRAD_MULTI") != nullptr;
+    if (_weights.size() > 1 && _net->fusion() && !noMulti) {
+        if (i > 0 && _wgradAllDone) {
+            if (i + 1 == (int)_weights.size()) _wgradAllDone = false;
+            return;
+        }
+        if (i == 0) {
+            const int cnt = (int)_weights.size();
+            std::vector<const float*> xs(cnt);
+            std::vector<float*> ts(cnt);
+            std::vector<int> is(cnt);
+            std::vector<float> so(cnt), st(cnt);
+            bool all = cnt <= 4;
+            for (int k = 0; k < cnt && all; k++) {
+                Weights& wk = *_weights[k];
+                all = wk.eps() > 0;
+                xs[k] = _prev[k]->getActs();
+                ts[k] = wk.getGrad(dp);
+                is[k] = _prev[k]->outputs();
+                so[k] = gradScale(wk.eps(), pt);
+                st[k] = dp ? (wk.numUpdates() > 0 ? 1.f : 0.f) : ((wk.numUpdates() == 0 && pt != PASS_GC) ? wk.mom() : 0.f);
+            }
+            if (all && mcn_fc_bprop_weights_multi_supported(v, xs.data(), ts.data(), is.data(), cnt, _outputs, n) == 1) {
+                chk(mcn_fc_bprop_weights_multi(v, xs.data(), ts.data(), is.data(), so.data(), st.data(), cnt, _outputs, n, _net->stream()),
+                    "fc bprop weights (all inputs)");
+                _wgradAllDone = true;
+                return;
+            }
+        }
+    }
+    Weights& w = *_weights[i];
     // single GPU: momentum folded into the GEMM epilogue (layer.cu:378-381); data-parallel: raw
     // scaled gradient, momentum applied after the all-reduce (algebraically identical)
     const float scaleTgt = dp ? (w.numUpdates() > 0 ? 1.f : 0.f) : ((w.numUpdates() == 0 && pt != PASS_GC) ? w.mom() : 0.f);

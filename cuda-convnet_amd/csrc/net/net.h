@@ -222,7 +222,7 @@ class FCLayer : public WeightLayer {
     void bpropBiases(float* v, PassType) override;
     void biasSumShape(int numCases, int& rows, int& cols) const override { rows = _outputs; cols = numCases; }
     void bpropWeights(float* v, int, PassType) override;
-    bool _fwdAllDone = false;
+    bool _fwdAllDone = false, _wgradAllDone = false;
     std::vector<char> _bwdDone;
 };
 

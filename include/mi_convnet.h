@@ -276,6 +276,16 @@ int mcn_fc_bprop_acts_multi_supported(const float* const* weights, float* const*
 int mcn_fc_bprop_acts_multi(const float* const* weights, float* const* targets, const int* numInputs, const float* scaleTargets,
                             const float* const* neuronActs, const int* neuronTypes, const float* neuronA, const float* neuronB,
                             int count, const float* actsGrad, int numOutputs, int numCases, void* stream);
+/* FCLayer::bpropWeights over ALL inputs of the layer in one launch (layer.cu:372-382 issues one addProduct per input):
+ * targets[i] (numOutputs x numInputs[i], row-major = the memory image of the reference's Fortran-order (inputs, outputs)
+ * matrix) = scaleTargets[i]*targets[i] + scaleOutput[i] * actsGrad (numOutputs, numCases) * inputs[i]^T (numInputs[i], numCases).
+ * The pointer / scale arrays are host arrays of `count` entries.  Shapes: numCases a multiple of 4, every numInputs[i]
+ * even, operands 16-byte aligned, count <= 4 (see ..._supported). */
+int mcn_fc_bprop_weights_multi_supported(const float* actsGrad, const float* const* inputs, float* const* targets,
+                                         const int* numInputs, int count, int numOutputs, int numCases);
+int mcn_fc_bprop_weights_multi(const float* actsGrad, const float* const* inputs, float* const* targets, const int* numInputs,
+                               const float* scaleOutput, const float* scaleTargets, int count, int numOutputs, int numCases,
+                               void* stream);
 /* addVector (nvmatrix.cu:652-690): mat(rows x cols) += scale*vec; perRow=1: vec[rows], 0: vec[cols]. */
 int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream);
 /* addSum (nvmatrix.cu:896-906 -> _aggregate :700-805): tgt = scaleThis*tgt + scaleSum*sum(mat, axis).

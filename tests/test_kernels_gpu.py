@@ -992,3 +992,24 @@ def test_add_sum_multi_equals_per_matrix_add_sum():
         close(got, ref.astype(np.float32), rtol=2e-5, what='row sums %r' % (shp,))
     with pytest.raises(Exception):
         L.call('mcn_add_sum_multi', C.cast(items, C.c_void_p), 9, ws, nb, None)
+
+
+@pytest.mark.parametrize('O_,Is,N', [(160, (1024, 1200), 128), (160, (768, 960), 128), (160, (1024,), 96), (512, (512, 2048), 128),
+                                      (50, (34, 6, 130), 36)])
+def test_fc_bprop_weights_all_inputs_in_one_launch(O_, Is, N):
+    """mcn_fc_bprop_weights_multi == one NT product per input (FCLayer::bpropWeights, layer.cu:372-382): momentum-scaled old
+    increment plus eps/N times dY X_i^T, each input with its own scales; ragged tiles in every dimension."""
+    rng = np.random.default_rng(183)
+    dY = mk(rng, O_, N)
+    Xs = [mk(rng, I, N) for I in Is]
+    t0 = [mk(rng, O_, I, scale=0.01) for I in Is]
+    alphas = [5e-4 / N * (k + 1) for k in range(len(Is))]
+    betas = [0.9, 0.0, 0.5, 1.0][:len(Is)]
+    wants = [O.gemm(dY, X, O_, I, N, tb=True, alpha=a, beta=b, Cmat=t.copy()) for X, I, a, b, t in zip(Xs, Is, alphas, betas, t0)]
+    dX, dT = [dev(x) for x in Xs], [dev(t) for t in t0]
+    xa, ta_, ka = ptr_array(dX), ptr_array(dT), (C.c_int * len(Is))(*Is)
+    d_dy = dev(dY)
+    assert capi.lib().raw('mcn_fc_bprop_weights_multi_supported')(d_dy.ptr, xa, ta_, ka, len(Is), O_, N) == 1
+    call('mcn_fc_bprop_weights_multi', d_dy, xa, ta_, ka, (C.c_float * len(Is))(*alphas), (C.c_float * len(Is))(*betas), len(Is), O_, N, None)
+    for i in range(len(Is)):
+        close(dT[i].numpy(), wants[i], what='dW[%d]' % i)
