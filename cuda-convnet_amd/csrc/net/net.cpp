@@ -1702,10 +1702,11 @@ void ConvNet::waitSideSubmitted(long ticket) {
 // Bias gradients: row sums over 0.1-19 MB, one or two launches of 2-5 us per layer (eight per DeepID2 step, ~30 us of the
 // side stream).  A single-GPU pass queues them and the last weight layer's bias piece (side stream) issues all of them as
 // one mcn_add_sum_multi (two launches); what a pass leaves queued (its first pass, before the number of weight layers is
-// known) is issued by bprop() itself.  Data parallel: per layer as before, the buckets of the exchange need them early.
+// known) is issued by bprop() itself.  Data parallel: a bucket of the exchange carries the bias gradients of its layers, so
+// whoever sends a bucket issues what is queued first (flushBuckets) -- one call per bucket instead of one or two per layer.
 bool ConvNet::biasBatching() const {
     static const bool off = getenv("MCN_NO_BIAS_BATCH") != nullptr;
-    return !off && _fusion && !_dpOn;
+    return !off && _fusion;
 }
 void ConvNet::queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum) {
     _biasBatch[t_stream == 1 ? 1 : 0].push_back({tgt, mat, rows, cols, scaleSum});
@@ -2109,6 +2110,7 @@ void ConvNet::flushBuckets(bool force) {
     }
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
+    if (t_stream == 1) flushBiasSums();  // (the bias gradients of this bucket's layers, queued by this thread, on this stream)
     // the exchange waits for the stream(s) that hold the kernels writing this bucket (a record + wait pair costs ~16 us
     // of host time, so only where needed; force: whatever is left, written by either stream)
     bool onMain = force, onSide = force && _gradPending;
