@@ -319,6 +319,33 @@ int mcn_sum_all(const float* a, size_t n, double* outDevice, int accumulate, voi
 /* NVMatrix::transpose (hard transpose, worker.cu:201-208): dst (cols x rows) = src(rows x cols)^T */
 int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 
+/* ---- image-op layers outside the DeepID stacks (conv_util.cuh:38-52) ------------------------------
+ * All arrays (channels * pixels, numImages), images contiguous; rectangular maps where the reference is square-only.
+ * convBedOfNails / convBedOfNailsUndo (conv_util.cu:665-680): sub-sampling at startX + k*strideX in both directions;
+ * the undo zeroes the pixels between the nails when scaleTargets == 0 (the reference zeroes the matrix first) and leaves
+ * them alone otherwise. */
+int mcn_bed_of_nails(const float* images, float* target, int numImages, int numChannels, int imgSizeY, int imgSizeX, int startX,
+                     int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput, void* stream);
+int mcn_bed_of_nails_undo(const float* actsGrad, float* target, int numImages, int numChannels, int imgSizeY, int imgSizeX,
+                          int startX, int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput, void* stream);
+/* convGaussianBlur (conv_util.cuh:50, conv_util.cu:682-745): ONE direction of a separable blur with a symmetric filter of
+ * filterSize (odd) taps in device memory, zero outside the image.  Not in place (the reference's register queue allows
+ * target == images; here every output reads its neighbours from `images`). */
+int mcn_gaussian_blur(const float* images, const float* filter, float* target, int numImages, int numChannels, int imgSizeY,
+                      int imgSizeX, int filterSize, int horiz, float scaleTargets, float scaleOutput, void* stream);
+/* convResizeBilinear (conv_util.cu:2416-2468): square maps, imgSize ~ scale * tgtSize */
+int mcn_resize_bilinear(const float* images, float* target, int numImages, int numChannels, int imgSize, int tgtSize, float scale,
+                        void* stream);
+/* convRGBToYUV / convRGBToLAB (conv_util.cu:2470-2591): 3 channels in, 3 out; LAB raises to 0.3333 with the accurate powf
+ * where the reference uses the fast intrinsic */
+int mcn_rgb_to_yuv(const float* images, float* target, int numImages, int imgPixels, void* stream);
+int mcn_rgb_to_lab(const float* images, float* target, int numImages, int imgPixels, int center, void* stream);
+/* convShift (conv_util.cuh:52, conv_util.cu:2902-2990; on the HOST in the reference): a gather of pixels,
+ * target[(f*numChannels + c)*tgtPixels + i, n] = images[c*imgPixels + int(filter[i*numFilters + f]), n];
+ * filter (tgtPixels, numFilters) holds source pixel indices as floats, in device memory (indices are clamped to the image). */
+int mcn_shift(const float* images, const float* filter, float* target, int numImages, int numChannels, int imgPixels, int tgtPixels,
+              int numFilters, void* stream);
+
 /* ---- layer_kernels.cuh:39-56 and SoftmaxLayer (layer.cu:585-595) ---------------------------- */
 size_t mcn_softmax_workspace_bytes(int numOut, int numCases);
 int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes,

@@ -682,3 +682,119 @@ ORC void orc_sgd_update(float* W, float* inc, const float* grad, size_t n, float
 }
 
 ORC int orc_version() { return 1; }
+
+// ---------------------------------------------------------------------------
+// Image-op layers outside the DeepID stacks.
+// ---------------------------------------------------------------------------
+// convBedOfNails / convBedOfNailsUndo (conv_util.cu:461-556 kernel, host :561-680): the undo host code zeroes the
+// target when scaleTargets == 0 (:673-676) and the kernel then touches the nail positions only.
+ORC void orc_bed_of_nails(const float* imgs, float* target, int numImages, int numChannels, int imgSizeY, int imgSizeX,
+                          int startX, int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput) {
+    for (int c = 0; c < numChannels; c++)
+        for (int oy = 0; oy < outputsY; oy++)
+            for (int ox = 0; ox < outputsX; ox++) {
+                const float* s = imgs + ((size_t)c * imgSizeY * imgSizeX + (size_t)(startX + oy * strideX) * imgSizeX + startX + ox * strideX) * numImages;
+                float* t = target + ((size_t)c * outputsY * outputsX + (size_t)oy * outputsX + ox) * numImages;
+                for (int n = 0; n < numImages; n++) t[n] = scaleTargets != 0 ? scaleTargets * t[n] + scaleOutput * s[n] : scaleOutput * s[n];
+            }
+}
+ORC void orc_bed_of_nails_undo(const float* grads, float* target, int numImages, int numChannels, int imgSizeY, int imgSizeX,
+                               int startX, int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput) {
+    const size_t total = (size_t)numChannels * imgSizeY * imgSizeX * numImages;
+    if (scaleTargets == 0) for (size_t i = 0; i < total; i++) target[i] = 0.f;
+    for (int c = 0; c < numChannels; c++)
+        for (int oy = 0; oy < outputsY; oy++)
+            for (int ox = 0; ox < outputsX; ox++) {
+                const float* g = grads + ((size_t)c * outputsY * outputsX + (size_t)oy * outputsX + ox) * numImages;
+                float* t = target + ((size_t)c * imgSizeY * imgSizeX + (size_t)(startX + oy * strideX) * imgSizeX + startX + ox * strideX) * numImages;
+                for (int n = 0; n < numImages; n++) t[n] = scaleTargets * t[n] + scaleOutput * g[n];  // (target was zeroed when scaleTargets == 0)
+            }
+}
+// kGaussianBlur (conv_util.cu:356-448), restated with its own data flow: a queue of 2*radius partial outputs that every
+// pixel of a line adds to (taps 0 .. 2*radius-1; the last tap enters through the symmetry f[2r] == f[0], :418), the head
+// of the queue leaving as a finished output once `radius` pixels are in.  Lines run along x (horiz) or y.
+ORC void orc_gaussian_blur(const float* imgs, const float* filter, float* target, int numImages, int numChannels, int imgSizeY,
+                           int imgSizeX, int filterSize, int horiz, float scaleTargets, float scaleOutput) {
+    const int radius = filterSize / 2, len = horiz ? imgSizeX : imgSizeY, lines = horiz ? imgSizeY : imgSizeX;
+    const size_t step = (size_t)(horiz ? 1 : imgSizeX) * numImages, lineStep = (size_t)(horiz ? imgSizeX : 1) * numImages;
+    std::vector<float> out(2 * radius + 1);
+    for (int c = 0; c < numChannels; c++)
+        for (int l = 0; l < lines; l++)
+            for (int n = 0; n < numImages; n++) {
+                const float* s = imgs + (size_t)c * imgSizeY * imgSizeX * numImages + l * lineStep + n;
+                float* t = target + (size_t)c * imgSizeY * imgSizeX * numImages + l * lineStep + n;
+                std::fill(out.begin(), out.end(), 0.f);
+                int written = 0;
+                auto emit = [&](float v) {
+                    float* d = t + (size_t)written * step;
+                    *d = scaleTargets != 0 ? scaleTargets * *d + scaleOutput * v : scaleOutput * v;
+                    written++;
+                };
+                const int lead = radius < len ? radius : len;
+                for (int col = 0; col < lead; col++) {  // :395-402
+                    const float px = s[(size_t)col * step];
+                    for (int r = 0; r < radius + 1 + col && r < 2 * radius; r++) out[r] += px * filter[radius + col - r];
+                }
+                for (int col = lead; col < len; col++) {  // :405-418 / :427-437
+                    const float px = s[(size_t)col * step];
+                    emit(out[0] + px * filter[0]);
+                    for (int r = 1; r < 2 * radius; r++) out[r - 1] = out[r] + px * filter[r];
+                    out[2 * radius - 1] = px * filter[0];
+                }
+                for (int r = 0; r < radius && written < len; r++) emit(out[r]);  // :420-424 / :439-442
+            }
+}
+// kResizeBilinear (conv_util.cu:288-340), centerScale from the host code (:2427-2429)
+ORC void orc_resize_bilinear(const float* imgs, float* target, int numImages, int numChannels, int imgSize, int tgtSize, float scale) {
+    const float centerScale = (float)(imgSize * 0.5 - tgtSize * 0.5 * (double)scale);
+    for (int c = 0; c < numChannels; c++)
+        for (int pxY = 0; pxY < tgtSize; pxY++)
+            for (int pxX = 0; pxX < tgtSize; pxX++) {
+                const float srcPxX = fmaxf(0.0f, fminf((float)imgSize - 1.01f, (float)pxX * scale + centerScale));
+                const float srcPxY = fmaxf(0.0f, fminf((float)imgSize - 1.01f, (float)pxY * scale + centerScale));
+                const float u = floorf(srcPxX + 1) - srcPxX, w = srcPxY - floorf(srcPxY);
+                const int p0 = (int)floorf(srcPxY) * imgSize + (int)floorf(srcPxX);
+                const float* s = imgs + (size_t)c * imgSize * imgSize * numImages;
+                float* t = target + ((size_t)c * tgtSize * tgtSize + (size_t)pxY * tgtSize + pxX) * numImages;
+                for (int n = 0; n < numImages; n++) {
+                    const float v0 = s[(size_t)p0 * numImages + n], v1 = s[(size_t)(p0 + 1) * numImages + n];
+                    const float v2 = s[(size_t)(p0 + imgSize) * numImages + n], v3 = s[(size_t)(p0 + imgSize + 1) * numImages + n];
+                    const float c0 = u * (v0 - v1) + v1, c1 = u * (v2 - v3) + v3;
+                    t[n] = w * (c1 - c0) + c0;
+                }
+            }
+}
+// kRGBToYUV (conv_util.cu:170-196) / kRGBToLAB (:198-277)
+ORC void orc_rgb_to_yuv(const float* imgs, float* target, int numImages, int imgPixels) {
+    const size_t cs = (size_t)imgPixels * numImages;
+    for (size_t i = 0; i < cs; i++) {
+        const float R = imgs[i], G = imgs[cs + i], B = imgs[2 * cs + i];
+        target[i] = 0.2126f * R + 0.7152f * G + 0.0722f * B;
+        target[cs + i] = -0.09991f * R + -0.33609f * G + 0.436f * B;
+        target[2 * cs + i] = 0.615f * R + -0.55861f * G + -0.05639f * B;
+    }
+}
+static inline float orc_labf(float x) { return x > 0.0088564517f ? powf(x, 0.3333f) : 7.787037f * x + 0.13793103f; }
+ORC void orc_rgb_to_lab(const float* imgs, float* target, int numImages, int imgPixels, int center) {
+    const size_t cs = (size_t)imgPixels * numImages;
+    for (size_t i = 0; i < cs; i++) {
+        const float R = imgs[i], G = imgs[cs + i], B = imgs[2 * cs + i];
+        const float X = 0.49f * R + 0.31f * G + 0.2f * B, Y = 0.17697f * R + 0.8124f * G + 0.01063f * B, Z = 0.01f * G + 0.99f * B;
+        const float lx = orc_labf(X), ly = orc_labf(Y), lz = orc_labf(Z);
+        target[i] = 116.0f * ly - 16.0f - (center ? 50.0f : 0.f);
+        target[cs + i] = 500.0f * (lx - ly);
+        target[2 * cs + i] = 200.0f * (ly - lz);
+    }
+}
+// convShift (conv_util.cu:2902-2990): the host loop of the reference
+ORC void orc_shift(const float* imgs, const float* filter, float* target, int numImages, int numChannels, int imgPixels, int tgtPixels,
+                   int numFilters) {
+    for (int n = 0; n < numImages; n++)
+        for (int c = 0; c < numChannels; c++)
+            for (int f = 0; f < numFilters; f++)
+                for (int i = 0; i < tgtPixels; i++) {
+                    const size_t y = (size_t)f * numChannels * tgtPixels + (size_t)c * tgtPixels + i;
+                    const size_t dy = (size_t)c * imgPixels + (size_t)(int)filter[(size_t)i * numFilters + f];
+                    target[y * numImages + n] = imgs[dy * numImages + n];
+                }
+}

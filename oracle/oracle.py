@@ -283,3 +283,52 @@ def fisher2_grad(labels, data, D, N, alpha, coeff, target=None, add=False):
         target = np.zeros((D, N), np.float32)
     lib().orc_fisher2_grad(_p(_c(labels)), _p(_c(data)), _p(target), D, N, _f(alpha), int(add), _f(coeff))
     return target
+
+
+# ---- image-op layers outside the DeepID stacks
+def bed_of_nails(imgs, N, C_, imgY, imgX, start, stride, outY, outX, target=None, sT=0.0, sO=1.0):
+    if target is None:
+        target = np.zeros((C_ * outY * outX, N), np.float32)
+    lib().orc_bed_of_nails(_p(imgs), _p(target), N, C_, imgY, imgX, start, stride, outY, outX, _f(sT), _f(sO))
+    return target
+
+
+def bed_of_nails_undo(grads, N, C_, imgY, imgX, start, stride, outY, outX, target=None, sT=0.0, sO=1.0):
+    if target is None:
+        target = np.zeros((C_ * imgY * imgX, N), np.float32)
+    lib().orc_bed_of_nails_undo(_p(grads), _p(target), N, C_, imgY, imgX, start, stride, outY, outX, _f(sT), _f(sO))
+    return target
+
+
+def gaussian_blur(imgs, filt, N, C_, imgY, imgX, horiz, target=None, sT=0.0, sO=1.0):
+    if target is None:
+        target = np.zeros((C_ * imgY * imgX, N), np.float32)
+    filt = np.ascontiguousarray(filt, np.float32).ravel()
+    lib().orc_gaussian_blur(_p(imgs), _p(filt), _p(target), N, C_, imgY, imgX, filt.size, int(horiz), _f(sT), _f(sO))
+    return target
+
+
+def resize_bilinear(imgs, N, C_, img_size, tgt_size, scale):
+    target = np.empty((C_ * tgt_size * tgt_size, N), np.float32)
+    lib().orc_resize_bilinear(_p(imgs), _p(target), N, C_, img_size, tgt_size, _f(scale))
+    return target
+
+
+def rgb_to_yuv(imgs, N, pixels):
+    target = np.empty((3 * pixels, N), np.float32)
+    lib().orc_rgb_to_yuv(_p(imgs), _p(target), N, pixels)
+    return target
+
+
+def rgb_to_lab(imgs, N, pixels, center):
+    target = np.empty((3 * pixels, N), np.float32)
+    lib().orc_rgb_to_lab(_p(imgs), _p(target), N, pixels, int(center))
+    return target
+
+
+def shift(imgs, filt, N, C_, img_pixels):
+    filt = np.ascontiguousarray(filt, np.float32)
+    tgt_pixels, nf = filt.shape
+    target = np.empty((nf * C_ * tgt_pixels, N), np.float32)
+    lib().orc_shift(_p(imgs), _p(filt), _p(target), N, C_, img_pixels, tgt_pixels, nf)
+    return target
