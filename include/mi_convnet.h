@@ -188,6 +188,57 @@ int mcn_conv_weight_acts_reduced_static(const float* images, const float* hidAct
                                         int paddingStart, int moduleStride, int numGroups,
                                         float scaleTargets, float scaleOutput, void* stream);
 
+/* ---- random-sparse connectivity (cudaconv2.cuh:80-124) ----------------------------------------------
+ * Filter group g reads the numFilterColors image channels colorIndices[g*numFilterColors ..] (device ints; a concatenation
+ * of overSample = numGroups*numFilterColors/numImgColors permutations of the image channels, layer.py:830-853).  filters
+ * are (numFilterColors*filterPixels, numFilters) [conv] / (modules*numFilterColors*filterPixels, numFilters) [local], as in
+ * the reference.  The channel table is applied once per call by a streaming pass into `workspace`, the product is the dense
+ * grouped kernel over the re-ordered tensor (sparse_conv.hip).
+ * conv/localFilterActsSparse (cudaconv2.cuh:80-94, filter_acts.cu:1221-1444) and conv/localWeightActsSparse
+ * (cudaconv2.cuh:96-108): workspace >= mcn_sparse_gathered_bytes().
+ * conv/localImgActsSparse (cudaconv2.cuh:110-124, img_acts.cu:1929-2583): workspace >= mcn_sparse_img_acts_workspace_bytes();
+ * targets is (numImgColors*imgPixels, numImages) = scaleTargets*targets + scaleOutput * (sum over the overSample copies) --
+ * the reference writes the (overSample, numImgColors, imgPixels, numImages) copies and its layer sums them (layer.cu:500-508,
+ * where the sum overwrites the target even when scaleTargets == 1). */
+size_t mcn_sparse_gathered_bytes(int numImages, int imgSizeY, int imgSizeX, int numFilterColors, int numGroups);
+size_t mcn_sparse_img_acts_workspace_bytes(int numImages, int imgSizeY, int imgSizeX, int numFilterColors, int numGroups);
+int mcn_conv_filter_acts_sparse(const float* images, const float* filters, float* targets, const int* colorIndices, void* workspace,
+                                size_t workspaceBytes, int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                int numFilterColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                int paddingStart, int moduleStride, int numGroups, float scaleTargets, float scaleOutput, void* stream);
+int mcn_local_filter_acts_sparse(const float* images, const float* filters, float* targets, const int* colorIndices, void* workspace,
+                                 size_t workspaceBytes, int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                 int numFilterColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                 int paddingStart, int moduleStride, int numGroups, float scaleTargets, float scaleOutput, void* stream);
+int mcn_conv_img_acts_sparse(const float* hidActs, const float* filters, float* targets, const int* colorIndices, void* workspace,
+                             size_t workspaceBytes, int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilterColors,
+                             int numFilters, int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                             int numGroups, float scaleTargets, float scaleOutput, void* stream);
+int mcn_local_img_acts_sparse(const float* hidActs, const float* filters, float* targets, const int* colorIndices, void* workspace,
+                              size_t workspaceBytes, int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilterColors,
+                              int numFilters, int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                              int numGroups, float scaleTargets, float scaleOutput, void* stream);
+int mcn_conv_weight_acts_sparse(const float* images, const float* hidActs, float* targets, const int* colorIndices, void* workspace,
+                                size_t workspaceBytes, int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                int numFilterColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                int paddingStart, int moduleStride, int numGroups, int partialSum, float scaleTargets,
+                                float scaleOutput, void* stream);
+int mcn_local_weight_acts_sparse(const float* images, const float* hidActs, float* targets, const int* colorIndices, void* workspace,
+                                 size_t workspaceBytes, int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                                 int numFilterColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                 int paddingStart, int moduleStride, int numGroups, float scaleTargets, float scaleOutput,
+                                 void* stream);
+/* The passes themselves, for a layer graph that keeps the re-ordered tensor between forward and the weight gradient
+ * (no counterpart in the reference, whose kernels chase colorIndices in their inner loops, filter_acts.cu:401-560):
+ * target[k] = images[colorIndices[k]] for k < numIndices (a channel = imgPixels rows of numImages);
+ * inverse[s*numImgColors + colorIndices[s*numImgColors + j]] = s*numImgColors + j;
+ * target[c] = scaleTargets*target[c] + scaleOutput * sum_s gathered[inverse[s*numImgColors + c]]. */
+int mcn_gather_channels(const float* images, int imgStride, const int* colorIndices, float* target, int numImages, int numImgColors,
+                        int numIndices, int imgPixels, void* stream);
+int mcn_invert_channel_indices(const int* colorIndices, int* inverse, int numImgColors, int overSample, void* stream);
+int mcn_scatter_channels_sum(const float* gathered, const int* inverse, float* target, int numImages, int numImgColors, int overSample,
+                             int imgPixels, float scaleTargets, float scaleOutput, void* stream);
+
 /* ---- conv_util.cuh ---------------------------------------------------------------------- */
 /* convLocalPool<MaxPooler|AvgPooler> (conv_util.cuh:327-517). mode 0 = max, 1 = avg (clipped window). */
 int mcn_local_pool(const float* images, float* target, int numImages, int numFilters, int imgSizeY,

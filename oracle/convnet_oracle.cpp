@@ -40,12 +40,15 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 // host _filterActs :565-614).  targets = sT*targets + sO*(W (*) images).
 // images may be a column slice of a wider matrix: imgStride = row stride.
 // ---------------------------------------------------------------------------
-ORC void orc_filter_acts(const float* images, const float* filters, float* targets,
-                         int numImages, int imgStride, int imgSizeY, int imgSizeX,
-                         int numImgColors, int numFilters, int filterSize,
-                         int numModulesY, int numModulesX, int paddingStart, int moduleStride,
-                         int numGroups, float scaleTargets, float scaleOutput, int conv) {
-    const int fc = numImgColors / numGroups, fpg = numFilters / numGroups;
+// colorIndices != NULL: random-sparse connectivity (filter_acts.cu:401-560 filterActs_YxX_sparse_random): filter colour c of
+// group g reads image channel colorIndices[g*numFilterColors + c] (shColors, :467-470); numFilterColors is given.
+static void filter_acts_impl(const float* images, const float* filters, float* targets,
+                             int numImages, int imgStride, int imgSizeY, int imgSizeX,
+                             int numImgColors, int numFilters, int filterSize,
+                             int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                             int numGroups, float scaleTargets, float scaleOutput, int conv,
+                             const int* colorIndices, int numFilterColors) {
+    const int fc = colorIndices ? numFilterColors : numImgColors / numGroups, fpg = numFilters / numGroups;
     const int fp = filterSize * filterSize, M = numModulesY * numModulesX;
     const int imgPixels = imgSizeY * imgSizeX;
 #pragma omp parallel
@@ -66,7 +69,8 @@ ORC void orc_filter_acts(const float* images, const float* filters, float* targe
                             if (x < 0 || x >= imgSizeX) continue;
                             const size_t wrow = (size_t)(conv ? 0 : m) * fc * fp + (size_t)c * fp + fy * filterSize + fx;
                             const float w = filters[wrow * numFilters + f];
-                            const float* src = images + ((size_t)(g * fc + c) * imgPixels + (size_t)y * imgSizeX + x) * imgStride;
+                            const int ch = colorIndices ? colorIndices[g * fc + c] : g * fc + c;
+                            const float* src = images + ((size_t)ch * imgPixels + (size_t)y * imgSizeX + x) * imgStride;
                             float* a = acc.data();
                             for (int n = 0; n < numImages; n++) a[n] += w * src[n];
                         }
@@ -83,26 +87,51 @@ ORC void orc_filter_acts(const float* images, const float* filters, float* targe
     }
 }
 
+ORC void orc_filter_acts(const float* images, const float* filters, float* targets,
+                         int numImages, int imgStride, int imgSizeY, int imgSizeX,
+                         int numImgColors, int numFilters, int filterSize,
+                         int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                         int numGroups, float scaleTargets, float scaleOutput, int conv) {
+    filter_acts_impl(images, filters, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY,
+                     numModulesX, paddingStart, moduleStride, numGroups, scaleTargets, scaleOutput, conv, nullptr, 0);
+}
+// conv/localFilterActsSparse (filter_acts.cu:1221-1444)
+ORC void orc_filter_acts_sparse(const float* images, const float* filters, float* targets, const int* colorIndices,
+                                int numImages, int imgStride, int imgSizeY, int imgSizeX,
+                                int numImgColors, int numFilterColors, int numFilters, int filterSize,
+                                int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                int numGroups, float scaleTargets, float scaleOutput, int conv) {
+    filter_acts_impl(images, filters, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY,
+                     numModulesX, paddingStart, moduleStride, numGroups, scaleTargets, scaleOutput, conv, colorIndices, numFilterColors);
+}
+
 // ---------------------------------------------------------------------------
 // imgActs (img_acts.cu:52-188, :217-360, :392-518; host _imgActs :900-961).
 // targets[c,y,x,n] = sT*targets + sO * sum_{modules covering (y,x)} sum_f
 //                    hidActs[f,m,n] * W[(m),c,p(y,x,m),f]
 // ---------------------------------------------------------------------------
-ORC void orc_img_acts(const float* hidActs, const float* filters, float* targets,
-                      int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
-                      int filterSize, int numModulesY, int numModulesX, int paddingStart,
-                      int moduleStride, int numGroups, float scaleTargets, float scaleOutput, int conv) {
-    const int fc = numImgColors / numGroups, fpg = numFilters / numGroups;
+// colorIndices != NULL: img_acts_{mediumcolor,manycolor}_sparse_rand (img_acts.cu:556-700, :749-890): targets is
+// (overSample, numImgColors, imgPixels, numImages); copy s holds the contribution of groups [s*numGroups/overSample, ...),
+// whose filter colours are sent to the image channels colorIndices[g*numFilterColors + c] (one permutation per copy).
+static void img_acts_impl(const float* hidActs, const float* filters, float* targets,
+                          int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                          int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                          int moduleStride, int numGroups, float scaleTargets, float scaleOutput, int conv,
+                          const int* colorIndices, int numFilterColors) {
+    const int fc = colorIndices ? numFilterColors : numImgColors / numGroups, fpg = numFilters / numGroups;
     const int fp = filterSize * filterSize, M = numModulesY * numModulesX;
     const int imgPixels = imgSizeY * imgSizeX;
+    const int rows = colorIndices ? numGroups * numFilterColors : numImgColors;  // (copy, channel) pairs
+    std::vector<int> where(rows);  // target row (copy*numImgColors + channel) -> position g*fc + c in the table
+    for (int k = 0; k < rows; k++) where[colorIndices ? (k / numImgColors) * numImgColors + colorIndices[k] : k] = k;
 #pragma omp parallel
     {
         std::vector<float> acc(numImages);
 #pragma omp for collapse(2) schedule(static)
-        for (int cg = 0; cg < numImgColors; cg++) {
+        for (int cg = 0; cg < rows; cg++) {
             for (int px = 0; px < imgPixels; px++) {
                 const int y = px / imgSizeX, x = px % imgSizeX;
-                const int g = cg / fc, c = cg % fc;
+                const int g = where[cg] / fc, c = where[cg] % fc;
                 // module ranges exactly as img_acts.cu:435-440
                 const int startY = y - paddingStart < filterSize ? 0 : 1 + (y - paddingStart - filterSize) / moduleStride;
                 const int endY = imin(numModulesY, 1 + (y - paddingStart) / moduleStride);
@@ -135,17 +164,35 @@ ORC void orc_img_acts(const float* hidActs, const float* filters, float* targets
     }
 }
 
+ORC void orc_img_acts(const float* hidActs, const float* filters, float* targets,
+                      int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                      int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                      int moduleStride, int numGroups, float scaleTargets, float scaleOutput, int conv) {
+    img_acts_impl(hidActs, filters, targets, numImages, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY, numModulesX,
+                  paddingStart, moduleStride, numGroups, scaleTargets, scaleOutput, conv, nullptr, 0);
+}
+// conv/localImgActsSparse (img_acts.cu:1929-2583): targets (overSample*numImgColors*imgPixels, numImages)
+ORC void orc_img_acts_sparse(const float* hidActs, const float* filters, float* targets, const int* colorIndices,
+                             int numImages, int imgSizeY, int imgSizeX, int numImgColors, int numFilterColors, int numFilters,
+                             int filterSize, int numModulesY, int numModulesX, int paddingStart,
+                             int moduleStride, int numGroups, float scaleTargets, float scaleOutput, int conv) {
+    img_acts_impl(hidActs, filters, targets, numImages, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY, numModulesX,
+                  paddingStart, moduleStride, numGroups, scaleTargets, scaleOutput, conv, colorIndices, numFilterColors);
+}
+
 // ---------------------------------------------------------------------------
 // weightActs (weight_acts.cu:57-201, :233-380; host _weightActs :579-648).
 // conv:  targets[(m/partialSum), c, p, f] = sT*targets + sO * sum_{m in chunk} sum_n img*hid
 // local: partialSum == 1 and one slab per module (weight_acts.cu:966-976).
 // ---------------------------------------------------------------------------
-ORC void orc_weight_acts(const float* images, const float* hidActs, float* targets,
-                         int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
-                         int numFilters, int filterSize, int numModulesY, int numModulesX,
-                         int paddingStart, int moduleStride, int numGroups, int partialSum,
-                         float scaleTargets, float scaleOutput) {
-    const int fc = numImgColors / numGroups, fpg = numFilters / numGroups;
+// colorIndices != NULL: conv_weight_acts_mc_mf_rand (weight_acts.cu:414-560): the image channel of filter colour c of
+// group g is colorIndices[g*numFilterColors + c].
+static void weight_acts_impl(const float* images, const float* hidActs, float* targets,
+                             int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                             int numFilters, int filterSize, int numModulesY, int numModulesX,
+                             int paddingStart, int moduleStride, int numGroups, int partialSum,
+                             float scaleTargets, float scaleOutput, const int* colorIndices, int numFilterColors) {
+    const int fc = colorIndices ? numFilterColors : numImgColors / numGroups, fpg = numFilters / numGroups;
     const int fp = filterSize * filterSize, M = numModulesY * numModulesX;
     const int imgPixels = imgSizeY * imgSizeX;
     if (partialSum <= 0) partialSum = M;
@@ -162,7 +209,8 @@ ORC void orc_weight_acts(const float* images, const float* hidActs, float* targe
                     const int y = paddingStart + my * moduleStride + fy;
                     const int x = paddingStart + mx * moduleStride + fx;
                     if (y < 0 || y >= imgSizeY || x < 0 || x >= imgSizeX) continue;
-                    const float* src = images + ((size_t)(g * fc + c) * imgPixels + (size_t)y * imgSizeX + x) * imgStride;
+                    const int chn = colorIndices ? colorIndices[g * fc + c] : g * fc + c;
+                    const float* src = images + ((size_t)chn * imgPixels + (size_t)y * imgSizeX + x) * imgStride;
                     const float* h = hidActs + ((size_t)f * M + m) * numImages;
                     float d = 0.f;
 #pragma omp simd reduction(+ : d)
@@ -174,6 +222,24 @@ ORC void orc_weight_acts(const float* images, const float* hidActs, float* targe
             }
         }
     }
+}
+
+ORC void orc_weight_acts(const float* images, const float* hidActs, float* targets,
+                         int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors,
+                         int numFilters, int filterSize, int numModulesY, int numModulesX,
+                         int paddingStart, int moduleStride, int numGroups, int partialSum,
+                         float scaleTargets, float scaleOutput) {
+    weight_acts_impl(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY,
+                     numModulesX, paddingStart, moduleStride, numGroups, partialSum, scaleTargets, scaleOutput, nullptr, 0);
+}
+// conv/localWeightActsSparse (weight_acts.cu:978-1200)
+ORC void orc_weight_acts_sparse(const float* images, const float* hidActs, float* targets, const int* colorIndices,
+                                int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilterColors,
+                                int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                int paddingStart, int moduleStride, int numGroups, int partialSum,
+                                float scaleTargets, float scaleOutput) {
+    weight_acts_impl(images, hidActs, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors, numFilters, filterSize, numModulesY,
+                     numModulesX, paddingStart, moduleStride, numGroups, partialSum, scaleTargets, scaleOutput, colorIndices, numFilterColors);
 }
 
 // ---------------------------------------------------------------------------

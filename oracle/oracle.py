@@ -86,6 +86,62 @@ def weight_acts(images, hid, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, grou
     return targets
 
 
+def _pi(a):
+    assert isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def filter_acts_sparse(images, filters, conns, N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride, groups,
+                       targets=None, sT=0.0, sO=1.0, conv=True, img_stride=None):
+    """conv/localFilterActsSparse: conns (groups*fC,) int32 = colorIndices."""
+    if targets is None:
+        targets = np.zeros((F * mY * mX, N), np.float32)
+    lib().orc_filter_acts_sparse(_p(images), _p(filters), _p(targets), _pi(conns), N, img_stride or N, imgY, imgX, C_, fC, F, fs,
+                                 mY, mX, pad, stride, groups, _f(sT), _f(sO), int(conv))
+    return targets
+
+
+def img_acts_sparse(hid, filters, conns, N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride, groups, conv=True):
+    """conv/localImgActsSparse: the (overSample, C, pixels, N) copies the reference's kernel writes."""
+    over = groups * fC // C_
+    targets = np.zeros((over * C_ * imgY * imgX, N), np.float32)
+    lib().orc_img_acts_sparse(_p(hid), _p(filters), _p(targets), _pi(conns), N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride,
+                              groups, _f(0.0), _f(1.0), int(conv))
+    return targets
+
+
+def img_acts_sparse_summed(hid, filters, conns, N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride, groups,
+                           targets=None, sT=0.0, sO=1.0, conv=True):
+    """... followed by the sum over the copies that ConvLayer::bpropActs takes (layer.cu:500-508), with the accumulate
+    rule every other backward product has (the reference's sum overwrites the target even when scaleTargets == 1)."""
+    over = groups * fC // C_
+    copies = img_acts_sparse(hid, filters, conns, N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride, groups, conv)
+    acc = np.zeros((C_ * imgY * imgX, N), np.float32)
+    for s in range(over):
+        acc += copies.reshape(over, C_ * imgY * imgX, N)[s]
+    if targets is None or sT == 0.0:
+        out = np.float32(sO) * acc
+        if targets is not None:
+            targets[...] = out
+            return targets
+        return out
+    targets[...] = np.float32(sT) * targets + np.float32(sO) * acc
+    return targets
+
+
+def weight_acts_sparse(images, hid, conns, N, imgY, imgX, C_, fC, F, fs, mY, mX, pad, stride, groups, partial_sum=0,
+                       targets=None, sT=0.0, sO=1.0, conv=True, img_stride=None):
+    M = mY * mX
+    if not conv:
+        partial_sum = 1
+    ps = partial_sum if partial_sum > 0 else M
+    if targets is None:
+        targets = np.zeros(((M // ps) * fC * fs * fs, F), np.float32)
+    lib().orc_weight_acts_sparse(_p(images), _p(hid), _p(targets), _pi(conns), N, img_stride or N, imgY, imgX, C_, fC, F, fs, mY, mX,
+                                 pad, stride, groups, ps, _f(sT), _f(sO))
+    return targets
+
+
 def local_pool(imgs, N, F, imgY, imgX, subsX, start, stride, outY, outX, mode):
     target = np.empty((F * outY * outX, N), np.float32)
     lib().orc_local_pool(_p(imgs), _p(target), N, F, imgY, imgX, subsX, start, stride, outY, outX,
