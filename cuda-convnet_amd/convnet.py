@@ -213,6 +213,7 @@ PRESETS = {  # name: (layer def, layer params, provider kind, image geometry)
     'deepid-attr': ('deepid_attr_4131.cfg', 'deepid_attr_params.cfg', 'deepid_attr', (55, 55, 3)),
     'cifar10': ('cifar10.cfg', 'cifar10_params.cfg', 'cifar', (32, 32, 3)),
     'cifar10-cnorm': ('cifar10_cnorm.cfg', 'cifar10_params.cfg', 'cifar', (32, 32, 3)),
+    'cifar10-imgops': ('cifar10_imgops.cfg', 'cifar10_imgops_params.cfg', 'cifar', (32, 32, 3)),  # colour / resize / blur / nailbed / shift / randSparse
 }
 
 

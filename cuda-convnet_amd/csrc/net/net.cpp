@@ -564,9 +564,30 @@ LocalLayer::LocalLayer(ConvNet* net, const Params& p, bool useGrad, bool conv) :
     _modulesY = (int)pint(p, "modulesY", _modulesX);
     _modules = (int)pint(p, "modules");
     if (_modules != _modulesX * _modulesY) throw NetError("layer '" + _name + "': modules != modulesY*modulesX");
-    if (phas(p, "randSparse"))
-        for (long r : pintv(p, "randSparse"))
-            if (r) throw NetError("layer '" + _name + "': random-sparse connectivity is outside the scope of this build");
+    if (phas(p, "randSparse")) {  // layer.cu:410-418
+        std::vector<long> rs = pintv(p, "randSparse");
+        _sparse.resize(rs.size());
+        for (size_t i = 0; i < rs.size(); i++) {
+            if (!rs[i]) continue;
+            const Value& fc = pget(p, "filterConns");
+            if (fc.kind != Value::LIST || fc.list.size() <= i || fc.list[i].kind != Value::LIST)
+                throw NetError("layer '" + _name + "': 'filterConns' must hold one list of channel indices per input");
+            _sparse[i].reset(new Sparse);
+            for (const Value& e : fc.list[i].list) _sparse[i]->conns.push_back((int)(e.kind == Value::FLOAT ? (long)e.f : e.i));
+            const long wide = _groups[i] * _filterChannels[i];
+            if (_groups[i] < 2 || _filterChannels[i] % 4 || _channels[i] % _filterChannels[i] || wide % _channels[i] ||
+                (long)_sparse[i]->conns.size() != wide)
+                throw NetError("layer '" + _name + "': inconsistent random-sparse connectivity (layer.py:908-914)");
+            for (long s = 0; s < wide / _channels[i]; s++) {  // every run of `channels` entries is a permutation (layer.py:841-843)
+                std::vector<char> seen(_channels[i], 0);
+                for (long j = 0; j < _channels[i]; j++) {
+                    const int c = _sparse[i]->conns[s * _channels[i] + j];
+                    if (c < 0 || c >= _channels[i] || seen[c]) throw NetError("layer '" + _name + "': filterConns is not a list of channel permutations");
+                    seen[c] = 1;
+                }
+            }
+        }
+    }
     if (conv) {
         _partialSum = (int)pint(p, "partialSum");  // layer.cu:439-440
         _sharedBiases = (int)pint(p, "sharedBiases");
@@ -578,23 +599,56 @@ size_t LocalLayer::workspaceBytes(int maxCases) {
                                         : mcn_add_sum_workspace_bytes(_filters * _modules, maxCases, 1);
     if (_conv)
         for (size_t i = 0; i < _prev.size(); i++)
-            b = std::max(b, mcn_conv_weight_acts_reduced_workspace_bytes((int)_channels[i], _filters, (int)_filterSize[i], _modulesY,
-                                                                        _modulesX, (int)_groups[i]));
+            b = std::max(b, mcn_conv_weight_acts_reduced_workspace_bytes(sparse((int)i) ? wideChannels((int)i) : (int)_channels[i], _filters,
+                                                                        (int)_filterSize[i], _modulesY, _modulesX, (int)_groups[i]));
     return b;
+}
+
+void LocalLayer::allocate(int maxCases) {
+    WeightLayer::allocate(maxCases);
+    for (size_t i = 0; i < _sparse.size(); i++)
+        if (_sparse[i]) {
+            const size_t n = (size_t)wideChannels((int)i) * _imgSizeY[i] * _imgSizeX[i] * maxCases;
+            _sparse[i]->gathered.ensure(n);
+            if (_prev[i]->isGradConsumer()) _sparse[i]->gradTmp.ensure(n);
+        }
+}
+
+void LocalLayer::copyToGPU() {  // layer.cu:421-431
+    WeightLayer::copyToGPU();
+    for (size_t i = 0; i < _sparse.size(); i++)
+        if (_sparse[i]) {
+            Sparse& sp = *_sparse[i];
+            sp.dConns.ensure(sp.conns.size());
+            sp.dInverse.ensure(sp.conns.size());
+            chk(mcn_h2d(sp.dConns.p, sp.conns.data(), sp.conns.size() * sizeof(int), _net->stream()), "h2d filterConns");
+            chk(mcn_invert_channel_indices((const int*)sp.dConns.p, (int*)sp.dInverse.p, (int)_channels[i],
+                                           (int)(sp.conns.size() / _channels[i]), _net->stream()), "invert filterConns");
+            chk(mcn_stream_sync(_net->stream()), "sync");
+        }
 }
 
 void LocalLayer::fpropActs(int i, float scaleTargets, PassType) {  // layer.cu:443-462, :530-543
     const int n = _net->numCases();
+    const float* in = _inputs[i];
+    int channels = (int)_channels[i];
+    if (sparse(i)) {  // the channel table applied once; the product is the dense grouped one over the re-ordered input (sparse_conv.hip)
+        Sparse& sp = *_sparse[i];
+        channels = wideChannels(i);
+        chk(mcn_gather_channels(_inputs[i], n, (const int*)sp.dConns.p, sp.gathered.p, n, (int)_channels[i], channels,
+                                (int)(_imgSizeY[i] * _imgSizeX[i]), _net->stream()), "gather channels");
+        in = sp.gathered.p;
+    }
     if (scaleTargets == 0) {
         const bool fuse = fusedNeuron && _prev.size() == 1;
-        chk(mcn_filter_acts_bias_neuron(_inputs[i], _weights[i]->W(), _biases->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i],
-                                        (int)_channels[i], _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
+        chk(mcn_filter_acts_bias_neuron(in, _weights[i]->W(), _biases->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i],
+                                        channels, _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
                                         (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, (_conv && _sharedBiases) ? 0 : 1,
                                         fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT, fuse ? fusedNeuron->spec.a : 0.f,
                                         fuse ? fusedNeuron->spec.b : 0.f, _net->stream()), "filterActs");
     } else {
         auto fn = _conv ? mcn_conv_filter_acts : mcn_local_filter_acts;
-        chk(fn(_inputs[i], _weights[i]->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i], _filters,
+        chk(fn(in, _weights[i]->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], channels, _filters,
                (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], scaleTargets, 1.f,
                _net->stream()), "filterActs");
     }
@@ -603,6 +657,17 @@ void LocalLayer::fpropActs(int i, float scaleTargets, PassType) {  // layer.cu:4
 void LocalLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {  // layer.cu:498-513, :566-575
     // input = a max pool with non-overlapping windows, and every other consumer of that pool has already added its share:
     // the gradient goes through the pool (and the neuron under it) in the epilogue, never to the pool's own gradient matrix
+    auto fn = _conv ? mcn_conv_img_acts : mcn_local_img_acts;
+    if (sparse(i)) {  // layer.cu:499-508, :567-570: the dense grouped product, then every image channel collects its overSample copies
+        Sparse& sp = *_sparse[i];
+        chk(fn(v, _weights[i]->W(), sp.gradTmp.p, _net->numCases(), (int)_imgSizeY[i], (int)_imgSizeX[i], wideChannels(i), _filters,
+               (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], 0.f, 1.f, _net->stream()),
+            "imgActs (sparse)");
+        chk(mcn_scatter_channels_sum(sp.gradTmp.p, (const int*)sp.dInverse.p, _prev[i]->getActsGrad(), _net->numCases(), (int)_channels[i],
+                                     wideChannels(i) / (int)_channels[i], (int)(_imgSizeY[i] * _imgSizeX[i]), scaleTargets, 1.f,
+                                     _net->stream()), "scatter channels");
+        return;
+    }
     if (auto* pl = dynamic_cast<PoolLayer*>(_prev[i])) {
         if (pl->rcvdB() + 1 == pl->numGradProducersNext() && pl->prev()[0]->isGradConsumer() &&
             pl->undoFusable(_net->numCases(), (int)_channels[i], (int)_imgSizeY[i], (int)_imgSizeX[i])) {
@@ -616,7 +681,6 @@ void LocalLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {  // 
             return;
         }
     }
-    auto fn = _conv ? mcn_conv_img_acts : mcn_local_img_acts;
     chk(fn(v, _weights[i]->W(), _prev[i]->getActsGrad(), _net->numCases(), (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i],
            _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i], scaleTargets, 1.f,
            _net->stream()), "imgActs");
@@ -637,18 +701,21 @@ void LocalLayer::bpropWeights(float* v, int i, PassType pt) {
     const int n = _net->numCases();
     Weights& w = *_weights[i];
     const bool dp = _net->dataParallel();
+    // random-sparse input: the re-ordered tensor forward left behind, as numGroups*filterChannels dense grouped channels
+    const float* in = sparse(i) ? _sparse[i]->gathered.p : _prev[i]->getActs();
+    const int channels = sparse(i) ? wideChannels(i) : (int)_channels[i];
     if (_conv) {
         // layer.cu:476-496: weightActs into a (modules/partialSum) x weights temporary, then addSum over
         // its rows.  Here: one call with a private module split + fixed-order reduction; the value is
         // the sum over ALL modules either way, so `partialSum` only affects rounding order.
-        chk(mcn_conv_weight_acts_reduced(_prev[i]->getActs(), v, w.getGrad(dp), _net->workspace(), _net->workspaceBytes(), n, n,
-                                         (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i], _filters, (int)_filterSize[i],
+        chk(mcn_conv_weight_acts_reduced(in, v, w.getGrad(dp), _net->workspace(), _net->workspaceBytes(), n, n,
+                                         (int)_imgSizeY[i], (int)_imgSizeX[i], channels, _filters, (int)_filterSize[i],
                                          _modulesY, _modulesX, (int)_padding[i], (int)_stride[i], (int)_groups[i],
                                          w.numUpdates() > 0 ? 1.f : 0.f, gradScale(w.eps(), pt), _net->stream()), "convWeightActs");
     } else {
         // layer.cu:551-564: straight into inc with momentum (single GPU) / raw gradient (data-parallel)
         const float scaleTgt = dp ? (w.numUpdates() > 0 ? 1.f : 0.f) : ((pt != PASS_GC && w.numUpdates() == 0) ? w.mom() : 0.f);
-        chk(mcn_local_weight_acts(_prev[i]->getActs(), v, w.getGrad(dp), n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], (int)_channels[i],
+        chk(mcn_local_weight_acts(in, v, w.getGrad(dp), n, n, (int)_imgSizeY[i], (int)_imgSizeX[i], channels,
                                   _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i], (int)_stride[i],
                                   (int)_groups[i], scaleTgt, gradScale(w.eps(), pt), _net->stream()), "localWeightActs");
     }
@@ -802,6 +869,101 @@ void PoolLayer::bpropActs(float* v, int, float scaleTargets, PassType) {
         chk(mcn_local_max_undo(_prev[0]->getActs(), v, _acts, tgt, n, _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride, _outputsY,
                                _outputsX, scaleTargets, 1.f, _net->stream()), "max undo");
     }
+}
+
+// ============================================================================ image-op layers (layer.cu:743-840, :1124-1143)
+ImageOpLayer::ImageOpLayer(ConvNet* net, const Params& p) : Layer(net, p) {
+    _channels = (int)pint(p, "channels");
+    const int imgSize = (int)pint(p, "imgSize");
+    _imgSizeX = (int)pint(p, "imgSizeX", imgSize);
+    _imgSizeY = (int)pint(p, "imgSizeY", imgSize);
+}
+
+NailbedLayer::NailbedLayer(ConvNet* net, const Params& p) : ImageOpLayer(net, p) {
+    _start = (int)pint(p, "start");
+    _stride = (int)pint(p, "stride");
+    _outputsX = (int)pint(p, "outputsX");
+    _outputsY = (int)pint(p, "outputsY", _outputsX);
+}
+void NailbedLayer::fpropActs(int, float, PassType) {  // layer.cu:751-753
+    chk(mcn_bed_of_nails(_inputs[0], _acts, _net->numCases(), _channels, _imgSizeY, _imgSizeX, _start, _stride, _outputsY, _outputsX, 0.f, 1.f,
+                         _net->stream()), "bedOfNails");
+}
+void NailbedLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // layer.cu:755-757
+    chk(mcn_bed_of_nails_undo(v, _prev[0]->getActsGrad(), _net->numCases(), _channels, _imgSizeY, _imgSizeX, _start, _stride, _outputsY,
+                              _outputsX, scaleTargets, 1.f, _net->stream()), "bedOfNailsUndo");
+}
+
+GaussianBlurLayer::GaussianBlurLayer(ConvNet* net, const Params& p) : ImageOpLayer(net, p) {
+    _hFilter = pmat(p, "filter");
+    if (_hFilter.size() < 1 || _hFilter.size() % 2 == 0) throw NetError("layer '" + _name + "': the blur filter needs an odd number of taps");
+}
+void GaussianBlurLayer::allocate(int maxCases) {
+    Layer::allocate(maxCases);
+    _tmp.ensure((size_t)_outputs * maxCases);
+}
+void GaussianBlurLayer::copyToGPU() {  // layer.cu:782-784
+    _filter.ensure(_hFilter.size());
+    chk(mcn_h2d(_filter.p, _hFilter.data, _hFilter.size() * 4, _net->stream()), "h2d blur filter");
+    chk(mcn_stream_sync(_net->stream()), "sync");
+}
+void GaussianBlurLayer::fpropActs(int, float, PassType) {  // layer.cu:769-772: rows, then columns
+    const int n = _net->numCases(), fs = (int)_hFilter.size();
+    chk(mcn_gaussian_blur(_inputs[0], _filter.p, _tmp.p, n, _channels, _imgSizeY, _imgSizeX, fs, 1, 0.f, 1.f, _net->stream()), "blur rows");
+    chk(mcn_gaussian_blur(_tmp.p, _filter.p, _acts, n, _channels, _imgSizeY, _imgSizeX, fs, 0, 0.f, 1.f, _net->stream()), "blur columns");
+}
+void GaussianBlurLayer::bpropActs(float* v, int, float scaleTargets, PassType) {  // layer.cu:776-780: the filter is symmetric
+    const int n = _net->numCases(), fs = (int)_hFilter.size();
+    chk(mcn_gaussian_blur(v, _filter.p, _tmp.p, n, _channels, _imgSizeY, _imgSizeX, fs, 1, 0.f, 1.f, _net->stream()), "blur rows");
+    chk(mcn_gaussian_blur(_tmp.p, _filter.p, _prev[0]->getActsGrad(), n, _channels, _imgSizeY, _imgSizeX, fs, 0, scaleTargets, 1.f,
+                          _net->stream()), "blur columns");
+}
+
+ResizeLayer::ResizeLayer(ConvNet* net, const Params& p) : ImageOpLayer(net, p) {
+    _tgtSize = (int)pint(p, "tgtSize");
+    _scale = (float)pfloat(p, "scale");
+    if (_imgSizeX != _imgSizeY) throw NetError("layer '" + _name + "': resize needs square images");
+}
+void ResizeLayer::fpropActs(int, float, PassType) {  // layer.cu:798-800
+    chk(mcn_resize_bilinear(_inputs[0], _acts, _net->numCases(), _channels, _imgSizeX, _tgtSize, _scale, _net->stream()), "resizeBilinear");
+}
+void ResizeLayer::bpropActs(float*, int, float, PassType) {  // layer.cu:803-805 (assert(false))
+    throw NetError("layer '" + _name + "': a resize layer cannot propagate gradients");
+}
+
+ColorLayer::ColorLayer(ConvNet* net, const Params& p, bool lab) : ImageOpLayer(net, p), _lab(lab) {
+    if (lab) _center = (int)pint(p, "center", 0);
+    if (_channels != 3) throw NetError("layer '" + _name + "': colour transforms need 3 channels");
+}
+void ColorLayer::fpropActs(int, float, PassType) {  // layer.cu:815-817, :833-835
+    const int n = _net->numCases(), px = _imgSizeY * _imgSizeX;
+    if (_lab) chk(mcn_rgb_to_lab(_inputs[0], _acts, n, px, _center, _net->stream()), "rgbToLAB");
+    else chk(mcn_rgb_to_yuv(_inputs[0], _acts, n, px, _net->stream()), "rgbToYUV");
+}
+void ColorLayer::bpropActs(float*, int, float, PassType) {  // layer.cu:820-822, :838-840 (assert(false))
+    throw NetError("layer '" + _name + "': a colour transform cannot propagate gradients");
+}
+
+ShiftLayer::ShiftLayer(ConvNet* net, const Params& p) : ImageOpLayer(net, p) {
+    _hFilter = pmat(p, "filter");
+    if (_hFilter.fortran) throw NetError("layer '" + _name + "': the shift table must be C-contiguous");
+    const long px = (long)_imgSizeY * _imgSizeX;
+    if (_hFilter.rows * _hFilter.cols * _channels != _outputs) throw NetError("layer '" + _name + "': shift table does not match 'outputs'");
+    for (size_t k = 0; k < _hFilter.size(); k++)
+        if (!(_hFilter.data[k] >= 0 && _hFilter.data[k] < px)) throw NetError("layer '" + _name + "': shift table points outside the image");
+}
+void ShiftLayer::allocate(int maxCases) { Layer::allocate(maxCases); }
+void ShiftLayer::copyToGPU() {  // layer.cu:1141-1143
+    _filter.ensure(_hFilter.size());
+    chk(mcn_h2d(_filter.p, _hFilter.data, _hFilter.size() * 4, _net->stream()), "h2d shift table");
+    chk(mcn_stream_sync(_net->stream()), "sync");
+}
+void ShiftLayer::fpropActs(int, float, PassType) {  // layer.cu:1129-1131 (on the host in the reference, conv_util.cu:2902-2990)
+    chk(mcn_shift(_inputs[0], _filter.p, _acts, _net->numCases(), _channels, _imgSizeY * _imgSizeX, (int)_hFilter.rows, (int)_hFilter.cols,
+                  _net->stream()), "shift");
+}
+void ShiftLayer::bpropActs(float*, int, float, PassType) {  // layer.cu:1135-1139 is empty: the layer below would see an unwritten matrix
+    throw NetError("layer '" + _name + "': a shift layer cannot propagate gradients");
 }
 
 // ============================================================================ ResponseNormLayer (layer.cu:847-885)
@@ -1320,6 +1482,12 @@ ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int devic
         else if (t == "eltsum") l = new EltwiseSumLayer(this, p);
         else if (t == "eltmax") l = new EltwiseMaxLayer(this, p);
         else if (t == "neuron") l = new NeuronLayer(this, p);
+        else if (t == "nailbed") l = new NailbedLayer(this, p);
+        else if (t == "blur") l = new GaussianBlurLayer(this, p);
+        else if (t == "resize") l = new ResizeLayer(this, p);
+        else if (t == "rgb2yuv") l = new ColorLayer(this, p, false);
+        else if (t == "rgb2lab") l = new ColorLayer(this, p, true);
+        else if (t == "shift") l = new ShiftLayer(this, p);
         else if (t == "data") { auto* d = new DataLayer(this, p); _dataLayers.push_back(d); l = d; }
         else if (t == "cost.logreg") { auto* c = new LogregCostLayer(this, p); _costs.push_back(c); l = c; }
         else if (t == "cost.sum2") { auto* c = new SumOfSquaresCostLayer(this, p); _costs.push_back(c); l = c; }

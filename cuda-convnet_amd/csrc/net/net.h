@@ -242,6 +242,18 @@ class LocalLayer : public WeightLayer {
     bool _conv;
     std::vector<long> _padding, _stride, _filterSize, _channels, _imgSizeY, _imgSizeX, _groups, _filterChannels;
     int _filters, _modulesY, _modulesX, _modules, _partialSum = 0, _sharedBiases = 0;
+    // random-sparse connectivity (layer.cu:410-431): per input the channel table, its inverse, the re-ordered input kept from
+    // forward for the weight gradient, and the backward-data product before it is folded back onto the image channels
+    struct Sparse {
+        std::vector<int> conns;
+        DBuf dConns, dInverse, gathered, gradTmp;
+    };
+    std::vector<std::unique_ptr<Sparse>> _sparse;  // null: dense input
+    bool sparse(int i) const { return i < (int)_sparse.size() && _sparse[i]; }
+    int wideChannels(int i) const { return (int)(_groups[i] * _filterChannels[i]); }
+   public:
+    void allocate(int maxCases) override;
+    void copyToGPU() override;
 };
 
 class SoftmaxLayer : public Layer {
@@ -303,6 +315,67 @@ class PoolLayer : public Layer {
     void bpropActs(float* v, int, float, PassType) override;
     int _channels, _sizeX, _start, _stride, _outputsY, _outputsX, _imgSizeY, _imgSizeX;
     bool _max;
+};
+
+// ---- image-op layers (layer.cu:743-840, :1124-1143)
+class ImageOpLayer : public Layer {
+   public:
+    ImageOpLayer(ConvNet* net, const Params& p);
+   protected:
+    int _channels, _imgSizeY, _imgSizeX;
+};
+
+class NailbedLayer : public ImageOpLayer {
+   public:
+    NailbedLayer(ConvNet* net, const Params& p);
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    int _start, _stride, _outputsY, _outputsX;
+};
+
+class GaussianBlurLayer : public ImageOpLayer {
+   public:
+    GaussianBlurLayer(ConvNet* net, const Params& p);
+    void allocate(int maxCases) override;
+    void copyToGPU() override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float* v, int, float, PassType) override;
+    HostMat _hFilter;
+    DBuf _filter, _tmp;  // _tmp: the horizontally blurred image (the reference blurs its output in place, layer.cu:770-771)
+};
+
+class ResizeLayer : public ImageOpLayer {
+   public:
+    ResizeLayer(ConvNet* net, const Params& p);
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float*, int, float, PassType) override;
+    int _tgtSize;
+    float _scale;
+};
+
+class ColorLayer : public ImageOpLayer {  // RGBToYUVLayer / RGBToLABLayer
+   public:
+    ColorLayer(ConvNet* net, const Params& p, bool lab);
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float*, int, float, PassType) override;
+    bool _lab;
+    int _center = 0;
+};
+
+class ShiftLayer : public ImageOpLayer {
+   public:
+    ShiftLayer(ConvNet* net, const Params& p);
+    void allocate(int maxCases) override;
+    void copyToGPU() override;
+   protected:
+    void fpropActs(int, float, PassType) override;
+    void bpropActs(float*, int, float, PassType) override;
+    HostMat _hFilter;
+    DBuf _filter;
 };
 
 class ResponseNormLayer : public Layer {

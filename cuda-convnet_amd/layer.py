@@ -40,7 +40,7 @@ NEURONS = OrderedDict([
     ('tanh', (('a', 'b'), True, False)),
 ])
 
-UNSUPPORTED = ('nailbed', 'blur', 'resize', 'rgb2yuv', 'rgb2lab', 'rscale', 'shift')
+UNSUPPORTED = ('rscale',)   # parsed by the reference (layer.py:460-490) but unknown to its own initModel (convnet.cu:86-134)
 
 
 def parse_neuron(name, s):
@@ -234,7 +234,6 @@ def _parse_local(name, cfg, prev, ctx, conv):
     dic['initW'] = cfg.get_list(name, 'initW', float, 'floats')
     for k in ('channels', 'padding', 'stride', 'filterSize', 'filters', 'groups', 'randSparse', 'initW'):
         _check(len(dic[k]) == n_in, "Layer '%s': %s list length does not match number of inputs" % (name, k))
-    _check(not any(dic['randSparse']), "Layer '%s': randSparse connectivity is not supported by this build" % name)
     _check(min(dic['stride']) >= 1 and min(dic['filterSize']) >= 1 and min(dic['padding']) >= 0
            and min(dic['channels']) >= 1 and min(dic['groups']) >= 1, "Layer '%s': parameter out of range" % name)
 
@@ -248,6 +247,9 @@ def _parse_local(name, cfg, prev, ctx, conv):
                        for p, s, fs, st in zip(dic['padding'], img, dic['filterSize'], dic['stride'])]
     mx, my = mod(dic['imgSizeX']), mod(dic['imgSizeY'])
     dic['filterChannels'] = [c // g for c, g in zip(dic['channels'], dic['groups'])]
+    if any(dic['randSparse']):  # then filterChannels must be given for every input (layer.py:888-890)
+        dic['filterChannels'] = cfg.get_list(name, 'filterChannels', int, 'ints', default=dic['filterChannels'])
+        _check(len(dic['filterChannels']) == n_in, "Layer '%s': filterChannels list length does not match number of inputs" % name)
     _check(len(set(mx)) == 1 and len(set(my)) == 1 and len(set(dic['filters'])) == 1,
            "Layer '%s': all inputs must produce equally-dimensioned output." % name)
     dic['modulesX'], dic['modulesY'] = mx[0], my[0]
@@ -263,9 +265,19 @@ def _parse_local(name, cfg, prev, ctx, conv):
                "Layer '%s[%d]': number of channels must be smaller than 4 or divisible by 4" % (name, i))
         _check(dic['filterSize'][i] <= 2 * dic['padding'][i] + min(dic['imgSizeX'][i], dic['imgSizeY'][i]),
                "Layer '%s[%d]': filter size (%d) greater than image size + 2 * padding" % (name, i, dic['filterSize'][i]))
-        if dic['groups'][i] > 1:
-            _check(dic['channels'][i] % (4 * dic['groups'][i]) == 0, "Layer '%s[%d]': parameter 'channels' must be divisible by '4 * groups'" % (name, i))
-        _check(dic['channels'][i] % dic['groups'][i] == 0, "Layer '%s[%d]': parameter 'channels' must be divisible by 'groups'" % (name, i))
+        if dic['randSparse'][i]:  # random sparse connectivity, layer.py:908-914
+            ch, fch, grp = dic['channels'][i], dic['filterChannels'][i], dic['groups'][i]
+            _check(grp > 1, "Layer '%s[%d]': number of groups must be greater than 1 when using random sparse connectivity" % (name, i))
+            _check(fch >= 1 and ch % fch == 0, "Layer '%s[%d]': parameter 'channels' must be divisible by 'filterChannels'" % (name, i))
+            _check(fch % 4 == 0, "Layer '%s[%d]': parameter 'filterChannels' must be divisible by 4" % (name, i))
+            _check((grp * fch) % ch == 0, "Layer '%s[%d]': parameter 'groups * filterChannels' must be divisible by 'channels'" % (name, i))
+            _check(dic['weightSourceLayerIndices'][i] < 0, "Layer '%s[%d]': weight sharing with random sparse connectivity is not supported" % (name, i))
+            # gen_rand_conns, layer.py:830-833: overSample permutations of the channels (initCFunc is not supported)
+            dic['filterConns'][i] = [int(x) for _ in range(grp * fch // ch) for x in ctx.rng.permutation(ch)]
+        else:
+            if dic['groups'][i] > 1:
+                _check(dic['channels'][i] % (4 * dic['groups'][i]) == 0, "Layer '%s[%d]': parameter 'channels' must be divisible by '4 * groups'" % (name, i))
+            _check(dic['channels'][i] % dic['groups'][i] == 0, "Layer '%s[%d]': parameter 'channels' must be divisible by 'groups'" % (name, i))
         _check(dic['filters'] % (16 * dic['groups'][i]) == 0, "Layer '%s[%d]': parameter 'filters * groups' must be divisible by %d" % (name, i, 16 * dic['groups'][i]))
         dic['padding'][i] = -dic['padding'][i]  # layer.py:922
     dic['overSample'] = [g * fc // c for g, fc, c in zip(dic['groups'], dic['filterChannels'], dic['channels'])]
@@ -379,6 +391,107 @@ def _parse_norm(name, cfg, prev, ctx, cross):
     return dic
 
 
+def _no_grads_below(dic, prev):
+    """LayerWithInputParser.verify_no_grads, layer.py:363-365."""
+    _check(not _grad_consumers_below(dic, prev),
+           "Layer '%s': layers of type '%s' cannot propagate gradient and must not be placed over layers with parameters."
+           % (dic['name'], dic['type']))
+
+
+def _image_op(name, cfg, prev, channels=None):
+    """Common part of the image-op parsers (layer.py:367-530, :1161-1205): one input seen as `channels` maps."""
+    dic = _with_inputs(name, cfg, prev, 1)
+    dic['forceOwnActs'] = dic['usesActs'] = dic['usesInputs'] = False
+    dic['channels'] = cfg.get_int(name, 'channels') if channels is None else channels
+    _check(dic['channels'] >= 1, "Layer '%s': parameter 'channels' out of range" % name)
+    _check(dic['numInputs'][0] % dic['channels'] == 0,
+           "Layer '%s': has %d dimensional input, not interpretable as %d-channel images" % (name, dic['numInputs'][0], dic['channels']))
+    dic['imgPixels'] = dic['numInputs'][0] // dic['channels']
+    dic['imgSizeY'], dic['imgSizeX'] = _geom_of(prev[dic['inputs'][0]], dic['channels'])
+    dic['imgSize'] = dic['imgSizeX']
+    _check(dic['imgSizeY'] * dic['imgSizeX'] == dic['imgPixels'],
+           "Layer '%s': has %d dimensional input, not interpretable as %d-channel images" % (name, dic['numInputs'][0], dic['channels']))
+    return dic
+
+
+def _square(dic):
+    _check(dic['imgSizeY'] == dic['imgSizeX'], "Layer '%s': layers of type '%s' need square images" % (dic['name'], dic['type']))
+
+
+def _parse_nailbed(name, cfg, prev, ctx):  # NailbedLayerParser layer.py:367-394
+    dic = _image_op(name, cfg, prev)
+    dic['stride'] = cfg.get_int(name, 'stride')
+    _check(dic['stride'] >= 1, "Layer '%s': parameter 'stride' out of range" % name)
+    out = lambda s: (s + dic['stride'] - 1) // dic['stride']
+    dic['outputsX'], dic['outputsY'] = out(dic['imgSizeX']), out(dic['imgSizeY'])
+    dic['start'] = min(dic['imgSizeX'] - dic['stride'] * (dic['outputsX'] - 1), dic['imgSizeY'] - dic['stride'] * (dic['outputsY'] - 1)) // 2
+    dic['outputs'] = dic['channels'] * dic['outputsX'] * dic['outputsY']
+    dic['geom'] = (dic['channels'], dic['outputsY'], dic['outputsX'])
+    return dic
+
+
+def _parse_blur(name, cfg, prev, ctx):  # GaussianBlurLayerParser layer.py:396-428
+    dic = _image_op(name, cfg, prev)
+    dic['outputs'] = dic['numInputs'][0]
+    dic['filterSize'] = cfg.get_int(name, 'filterSize')
+    dic['stdev'] = cfg.get_float(name, 'stdev')
+    _check(dic['filterSize'] in (3, 5, 7, 9), "Layer '%s': parameter 'filterSize' must be one of 3, 5, 7, 9" % name)
+    _check(dic['stdev'] > 0, "Layer '%s': parameter 'stdev' must be positive" % name)
+    f = np.array([np.exp(-(dic['filterSize'] // 2 - i) ** 2 / float(2 * dic['stdev'] ** 2)) for i in range(dic['filterSize'])],
+                 dtype=np.float32).reshape(1, dic['filterSize'])
+    dic['filter'] = np.ascontiguousarray(f / f.sum(), dtype=np.float32)
+    _check(dic['filterSize'] <= min(dic['imgSizeX'], dic['imgSizeY']),
+           "Later '%s': filter size (%d) must be smaller than image size (%d)." % (name, dic['filterSize'], min(dic['imgSizeX'], dic['imgSizeY'])))
+    dic['geom'] = (dic['channels'], dic['imgSizeY'], dic['imgSizeX'])
+    return dic
+
+
+def _parse_resize(name, cfg, prev, ctx):  # ResizeLayerParser layer.py:430-458
+    dic = _image_op(name, cfg, prev)
+    _square(dic)
+    dic['scale'] = cfg.get_float(name, 'scale')
+    _check(0.5 <= dic['scale'] <= 2, "Layer '%s': parameter 'scale' must be in the range 0.5-2" % name)
+    dic['tgtSize'] = int(np.floor(dic['imgSize'] / dic['scale']))
+    dic['tgtPixels'] = dic['tgtSize'] ** 2
+    dic['outputs'] = dic['channels'] * dic['tgtPixels']
+    dic['geom'] = (dic['channels'], dic['tgtSize'], dic['tgtSize'])
+    dic['forceOwnActs'] = True   # every output reads four neighbours: never in the input's own matrix (scale == 1 would share it)
+    _no_grads_below(dic, prev)
+    return dic
+
+
+def _parse_colour(name, cfg, prev, ctx, lab):  # ColorTransformLayerParser layer.py:492-530
+    dic = _image_op(name, cfg, prev, channels=3)
+    dic['outputs'] = dic['numInputs'][0]
+    if lab:
+        dic['center'] = cfg.get_bool(name, 'center', default=False)
+    dic['geom'] = (3, dic['imgSizeY'], dic['imgSizeX'])
+    _no_grads_below(dic, prev)
+    return dic
+
+
+def _parse_shift(name, cfg, prev, ctx):  # ShiftLayerParser layer.py:1161-1205
+    dic = _image_op(name, cfg, prev)
+    _square(dic)
+    fs = dic['filterSize'] = cfg.get_int(name, 'filterSize')
+    _check(2 <= fs <= dic['imgSize'], "Later '%s': filter size (%d) must be smaller than image size (%d)." % (name, fs, dic['imgSize']))
+    out = dic['outputsX'] = dic['imgSize'] - fs + 1
+    dic['outputs'] = out ** 2 * dic['channels'] * (fs - 1) * (fs - 1)
+    filt = np.zeros((out * out, (fs - 1) * (fs - 1)), np.float32)
+    for dx in range(fs - 1):
+        for dy in range(fs - 1):
+            for x in range(out):
+                for y in range(out):
+                    filt[x * out + y, dx * (fs - 1) + dy] = (x + dx) * dic['imgSize'] + (y + dy)
+    dic['filter'] = filt
+    dic['forceOwnActs'] = True   # a gather: never in the input's own matrix
+    dic['geom'] = ((fs - 1) * (fs - 1) * dic['channels'], out, out)
+    # the reference's ShiftLayer::bpropActs is empty (layer.cu:1135-1139): whatever is below would train on an unwritten
+    # gradient matrix.  Refused here like the other layers that cannot propagate a gradient.
+    _no_grads_below(dic, prev)
+    return dic
+
+
 def _parse_cost(name, cfg, prev, ctx, num_inputs):
     dic = _with_inputs(name, cfg, prev, num_inputs)
     dic['requiresParams'] = True
@@ -412,6 +525,12 @@ PARSERS = {
     'rnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, False),
     'cmrnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, True),
     'cnorm': lambda n, c, p, x: _parse_norm(n, c, p, x, False),
+    'nailbed': _parse_nailbed,
+    'blur': _parse_blur,
+    'resize': _parse_resize,
+    'rgb2yuv': lambda n, c, p, x: _parse_colour(n, c, p, x, False),
+    'rgb2lab': lambda n, c, p, x: _parse_colour(n, c, p, x, True),
+    'shift': _parse_shift,
     'cost.logreg': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),
     'cost.sum2': lambda n, c, p, x: _parse_cost(n, c, p, x, 1),
     'cost.l2-sn': lambda n, c, p, x: _parse_cost(n, c, p, x, 2),

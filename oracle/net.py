@@ -259,10 +259,23 @@ class LocalLayer(WeightLayer):
                     fs=d['filterSize'][i], mY=d['modulesY'], mX=d['modulesX'], pad=d['padding'][i],
                     stride=d['stride'][i], groups=d['groups'][i])
 
+    def sparse(self, i):
+        return bool(self.d.get('randSparse', [False] * (i + 1))[i])
+
+    def sgeo(self, i):
+        """geometry + the channel table of a random-sparse input (layer.cu:410-431)"""
+        g = self.geo(i)
+        g['fC'] = self.d['filterChannels'][i]
+        return np.asarray(self.d['filterConns'][i], np.int32), g
+
     def fprop_acts(self, i, st, pt):  # layer.cu:443-462, :530-543
         d, n = self.d, self.net.num_cases
-        K.filter_acts(self.inputs[i], self.weights[i].W, n, targets=self.acts, sT=float(st), sO=1.0,
-                      conv=self.conv, **self.geo(i))
+        if self.sparse(i):
+            conns, g = self.sgeo(i)
+            K.filter_acts_sparse(self.inputs[i], self.weights[i].W, conns, n, targets=self.acts, sT=float(st), sO=1.0, conv=self.conv, **g)
+        else:
+            K.filter_acts(self.inputs[i], self.weights[i].W, n, targets=self.acts, sT=float(st), sO=1.0,
+                          conv=self.conv, **self.geo(i))
         if st == 0:
             if self.conv and d['sharedBiases']:
                 K.add_vector(self.acts, self.biases.W, d['filters'], d['modules'] * n, True)
@@ -278,8 +291,21 @@ class LocalLayer(WeightLayer):
             K.add_sum(self.biases.grad, v, d['filters'] * d['modules'], n, 1, 0.0, sc)
 
     def bprop_acts(self, v, i, st, pt):  # layer.cu:498-513, :566-575
+        if self.sparse(i):
+            conns, g = self.sgeo(i)
+            K.img_acts_sparse_summed(v, self.weights[i].W, conns, self.net.num_cases, targets=self.prev[i].get_acts_grad(),
+                                     sT=float(st), sO=1.0, conv=self.conv, **g)
+            return
         K.img_acts(v, self.weights[i].W, self.net.num_cases, targets=self.prev[i].get_acts_grad(),
                    sT=float(st), sO=1.0, conv=self.conv, **self.geo(i))
+
+    def weight_acts(self, i, *a, **kw):
+        if self.sparse(i):
+            conns, g = self.sgeo(i)
+            kw.update(g)
+            return K.weight_acts_sparse(a[0], a[1], conns, *a[2:], **kw)
+        kw.update(self.geo(i))
+        return K.weight_acts(*a, **kw)
 
 
 class ConvLayer(LocalLayer):
@@ -292,12 +318,12 @@ class ConvLayer(LocalLayer):
         ps = d['partialSum']
         scale_w = self.grad_scale(w.eps, pt)
         if ps > 0:
-            tmp = K.weight_acts(self.prev[i].acts, v, n, partial_sum=ps, sT=0.0, sO=scale_w, conv=True, **self.geo(i))
+            tmp = self.weight_acts(i, self.prev[i].acts, v, n, partial_sum=ps, sT=0.0, sO=scale_w, conv=True)
             rows = d['modules'] // ps
             K.add_sum(w.grad.reshape(-1), tmp, rows, tmp.size // rows, 0, 1.0 if w.num_updates > 0 else 0.0, 1.0)
         else:
-            K.weight_acts(self.prev[i].acts, v, n, partial_sum=0, targets=w.grad,
-                          sT=1.0 if w.num_updates > 0 else 0.0, sO=scale_w, conv=True, **self.geo(i))
+            self.weight_acts(i, self.prev[i].acts, v, n, partial_sum=0, targets=w.grad,
+                             sT=1.0 if w.num_updates > 0 else 0.0, sO=scale_w, conv=True)
 
 
 class LocalUnsharedLayer(LocalLayer):
@@ -312,8 +338,7 @@ class LocalUnsharedLayer(LocalLayer):
             scale_inc = 1.0 if w.num_updates > 0 else 0.0
         else:
             scale_inc = (1.0 if (pt != PASS_GC and w.num_updates == 0) else 0.0) * w.mom
-        K.weight_acts(self.prev[i].acts, v, n, targets=w.get_grad(dp), sT=scale_inc, sO=self.grad_scale(w.eps, pt), conv=False,
-                      **self.geo(i))
+        self.weight_acts(i, self.prev[i].acts, v, n, targets=w.get_grad(dp), sT=scale_inc, sO=self.grad_scale(w.eps, pt), conv=False)
 
 
 class SoftmaxLayer(Layer):
@@ -378,6 +403,63 @@ class PoolLayer(Layer):
             K.local_max_undo(self.prev[0].acts, v, self.acts, *self.args(), target=tgt, sT=float(st), sO=1.0)
         else:
             K.local_avg_undo(v, *self.args(), target=tgt, sT=float(st), sO=1.0)
+
+
+class NailbedLayer(Layer):
+    def args(self):
+        d = self.d
+        return (self.net.num_cases, d['channels'], d['imgSizeY'], d['imgSizeX'], d['start'], d['stride'], d['outputsY'], d['outputsX'])
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:751-753
+        self.acts[...] = K.bed_of_nails(self.inputs[0], *self.args())
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:755-757
+        K.bed_of_nails_undo(v, *self.args(), target=self.prev[0].get_acts_grad(), sT=float(st), sO=1.0)
+
+
+class GaussianBlurLayer(Layer):
+    def blur(self, x, target=None, st=0.0):
+        d, n = self.d, self.net.num_cases
+        f = np.ascontiguousarray(d['filter'], np.float32).reshape(-1)
+        rows = K.gaussian_blur(x, f, n, d['channels'], d['imgSizeY'], d['imgSizeX'], 1)
+        return K.gaussian_blur(rows, f, n, d['channels'], d['imgSizeY'], d['imgSizeX'], 0, target=target, sT=st, sO=1.0)
+
+    def fprop_acts(self, i, st, pt):  # layer.cu:769-772
+        self.acts[...] = self.blur(self.inputs[0])
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:776-780
+        self.blur(v, target=self.prev[0].get_acts_grad(), st=float(st))
+
+
+class ResizeLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:798-800
+        d = self.d
+        self.acts[...] = K.resize_bilinear(self.inputs[0], self.net.num_cases, d['channels'], d['imgSize'], d['tgtSize'], d['scale'])
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:803-805
+        raise AssertionError('resize layers cannot propagate gradients')
+
+
+class RGBToYUVLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:815-817
+        self.acts[...] = K.rgb_to_yuv(self.inputs[0], self.net.num_cases, self.d['imgPixels'])
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:820-822
+        raise AssertionError('colour transforms cannot propagate gradients')
+
+
+class RGBToLABLayer(RGBToYUVLayer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:833-835
+        self.acts[...] = K.rgb_to_lab(self.inputs[0], self.net.num_cases, self.d['imgPixels'], int(self.d['center']))
+
+
+class ShiftLayer(Layer):
+    def fprop_acts(self, i, st, pt):  # layer.cu:1129-1131
+        d = self.d
+        self.acts[...] = K.shift(self.inputs[0], np.ascontiguousarray(d['filter'], np.float32), self.net.num_cases, d['channels'], d['imgPixels'])
+
+    def bprop_acts(self, v, i, st, pt):  # layer.cu:1135-1139 (empty in the reference)
+        raise AssertionError('shift layers cannot propagate gradients')
 
 
 class ResponseNormLayer(Layer):
@@ -520,6 +602,8 @@ class L2regCostLayer(CostLayer):
 
 _TYPES = {'fc': FCLayer, 'conv': ConvLayer, 'local': LocalUnsharedLayer, 'pool': PoolLayer,
           'rnorm': ResponseNormLayer, 'cmrnorm': CrossMapResponseNormLayer, 'cnorm': ContrastNormLayer, 'softmax': SoftmaxLayer,
+          'nailbed': NailbedLayer, 'blur': GaussianBlurLayer, 'resize': ResizeLayer, 'rgb2yuv': RGBToYUVLayer,
+          'rgb2lab': RGBToLABLayer, 'shift': ShiftLayer,
           'eltsum': EltwiseSumLayer, 'eltmax': EltwiseMaxLayer, 'neuron': NeuronLayer, 'data': DataLayer,
           'cost.logreg': LogregCostLayer, 'cost.sum2': SumOfSquaresCostLayer, 'cost.l2-sn': L2SNCostLayer,
           'cost.l2-reg': L2regCostLayer, 'cost.fisher2': Fisher2CostLayer}

@@ -167,7 +167,7 @@ def test_checkpoint_layers_only_get_hyperparameters_refreshed():
 @pytest.mark.parametrize('edit,msg', [
     (('inputs=data', 'inputs=nosuch'), 'not defined'),
     (('neuron=relu', 'neuron=frobnicate'), 'unable to parse neuron'),
-    (('type=conv', 'type=nailbed'), 'outside the scope'),
+    (('type=conv', 'type=rscale'), 'outside the scope'),
     (('filters=16', 'filters=10'), 'divisible by 16'),
     (('partialSum=4', 'partialSum=7'), 'does not divide'),
 ])
@@ -178,6 +178,45 @@ def test_parser_errors(tmp_path, edit, msg):
     p.write_text(src.replace(edit[0], edit[1], 1))
     with pytest.raises(layer.LayerParsingError, match=msg):
         layer.parse_layers(str(p), os.path.join(HERE, 'cfg', 'gc_small_params.cfg'), {0: 432, 1: 1}, 10)
+
+
+def test_image_op_layers_and_random_sparse_connectivity_parse():
+    """The rarely-used layer types: dict schema of layer.py:367-530, :830-853, :1161-1205."""
+    by = {l['name']: l for l in parse('cifar10-imgops')}
+    assert (by['small']['tgtSize'], by['small']['outputs']) == (24, 3 * 24 * 24)                      # floor(32 / 1.3333)
+    assert by['lab']['center'] is True and by['lab']['channels'] == 3 and by['yuv']['outputs'] == 3072
+    f = by['blur1']['filter']
+    assert f.shape == (1, 5) and f.dtype == np.float32 and abs(float(f.sum()) - 1) < 1e-6 and np.allclose(f, f[:, ::-1])
+    n = by['nails']
+    assert (n['outputsX'], n['start'], n['outputs']) == (12, 1, 32 * 144)                              # layer.py:385-387
+    sh = by['shifted']
+    assert sh['outputsX'] == 30 and sh['outputs'] == 30 * 30 * 3 * 4 and sh['filter'].shape == (900, 4)
+    assert sh['filter'][31 * 1 + 0, 3] == (1 + 1) * 32 + (1 + 1)                                       # x=1, y=1, dx=dy=1 -> pixel (2, 2)... row x*out+y
+    c2 = by['conv2']
+    assert c2['randSparse'] == [True] and c2['filterChannels'] == [16] and c2['overSample'] == [2] and c2['filters'] == 64
+    conns = c2['filterConns'][0]
+    assert len(conns) == 64 and sorted(conns[:32]) == list(range(32)) and sorted(conns[32:]) == list(range(32))
+    assert c2['weights'][0].shape == (16 * 9, 64)
+    l3 = by['local3']
+    assert l3['overSample'] == [1] and sorted(l3['filterConns'][0]) == list(range(64)) and l3['weights'][0].shape == (16 * 32 * 9, 32)
+    for name in ('small', 'lab', 'yuv', 'shifted'):   # nothing with parameters below them (layer.py:363-365)
+        assert not by[name]['gradConsumer']
+
+
+@pytest.mark.parametrize('edit,msg', [
+    (('inputs=yuv\nchannels=3', 'inputs=conv1\nchannels=32'), 'cannot propagate gradient'),
+    (('groups=4\nfilterChannels=16', 'groups=1\nfilterChannels=16'), 'greater than 1 when using random sparse'),
+    (('groups=4\nfilterChannels=16', 'groups=4\nfilterChannels=6'), 'divisible'),
+    (('filterSize=5\nstdev=1.2', 'filterSize=4\nstdev=1.2'), 'must be one of 3, 5, 7, 9'),
+    (('scale=1.3333', 'scale=3'), 'range 0.5-2'),
+])
+def test_image_op_parser_errors(tmp_path, edit, msg):
+    src = open(os.path.join(CFG_DIR, PRESETS['cifar10-imgops'][0])).read()
+    assert edit[0] in src
+    p = tmp_path / 'bad.cfg'
+    p.write_text(src.replace(edit[0], edit[1], 1))
+    with pytest.raises(layer.LayerParsingError, match=msg):
+        layer.parse_layers(str(p), os.path.join(CFG_DIR, PRESETS['cifar10-imgops'][1]), {0: 3072, 1: 1}, 10)
 
 
 # ------------------------------------------------------------------------------------ data / sharding

@@ -89,7 +89,7 @@ def oracle_train(Lc, data, minibatch=128, test=False):
     return net, out
 
 
-@pytest.mark.parametrize('name', ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm'])
+@pytest.mark.parametrize('name', ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm', 'cifar10-imgops'])
 def test_train_3_steps_matches_oracle(name):
     """C1..C5: three consecutive minibatches of 128 through fprop/bprop/update, then syncWithHost."""
     dp, Lg = preset(name, 384)
@@ -514,7 +514,7 @@ def test_errors_are_exceptions_not_exits():
         lib.finishBatch()  # no model
     dp, Lg = preset('cifar10', 128)
     bad = copy.deepcopy(Lg)
-    bad[2]['type'] = 'nailbed'
+    bad[2]['type'] = 'rscale'   # parsed by the reference's layer.py, unknown to its initModel (convnet.cu:86-134)
     with pytest.raises(RuntimeError, match='Unknown layer type'):
         lib.initModel(bad, 128, 0)
     with Native(Lg) as lib:

@@ -23,7 +23,7 @@ from test_net_gpu import Native, preset  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-PRESET_NAMES = ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm']
+PRESET_NAMES = ['deepid-39x31', 'deepid', 'deepid2', 'deepid-attr', 'cifar10', 'deepid2plus', 'deepidn', 'cifar10-cnorm', 'cifar10-imgops']
 
 
 def rel_err(a, b):
