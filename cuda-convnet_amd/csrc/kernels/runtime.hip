@@ -4,6 +4,14 @@
 #include <stdarg.h>
 #include <string.h>
 #include "common.h"
+#include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 
 static thread_local char g_err[512] = "";
@@ -216,7 +224,149 @@ static int rccl_check(int rc, const char* what) {
     return MCN_ERCCL;
 }
 
+// ---------------------------------------------------------------------------
+// Rehearsal communicator for ranks that SHARE one GPU (MCN_COMM=shm).  RCCL refuses a second rank on a device
+// ("duplicate GPU"), so a one-GPU box can never run the data-parallel step with world > 1.  This transport lets it:
+// same entry points, same stream-ordered meaning, the payload staged through a POSIX shared-memory segment
+// (stream sync -> D2H into the rank's slot -> barrier -> every rank adds the slots in rank order -> H2D -> sync).
+// The sum has a fixed order, so all ranks end with bit-identical buffers, as with RCCL's ring on identical inputs.
+// It is a test transport (two PCIe trips and a host sum per collective) and is never selected unless asked for.
+// ---------------------------------------------------------------------------
+struct ShmHeader {
+    std::atomic<uint32_t> arrived, generation, attached;
+    uint32_t numRanks;
+    uint64_t slotBytes;
+};
+struct ShmComm {
+    int rank = 0, numRanks = 1;
+    size_t slotBytes = 0, mapBytes = 0;
+    ShmHeader* hdr = nullptr;
+    char* slots = nullptr;
+    float* bounce = nullptr;  // page-locked, slotBytes
+    char name[96] = {0};
+};
+struct McnComm {
+    rcclComm_t rccl = nullptr;
+    ShmComm* shm = nullptr;
+};
+static const char kShmTag[] = "MCNSHM:";
+static const size_t kShmSlotBytes = 8u << 20;
+static const size_t kShmHeaderBytes = 4096;
+
+static int shm_barrier(ShmComm* c, const char* what) {
+    const uint32_t gen = c->hdr->generation.load(std::memory_order_acquire);
+    if (c->hdr->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)c->numRanks) {
+        c->hdr->arrived.store(0, std::memory_order_relaxed);
+        c->hdr->generation.fetch_add(1, std::memory_order_acq_rel);
+        return MCN_OK;
+    }
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    for (unsigned spin = 0; c->hdr->generation.load(std::memory_order_acquire) == gen; spin++) {
+        if ((spin & 1023) == 1023) {
+            if (std::chrono::steady_clock::now() > deadline) {
+                mcn_set_error("%s: a peer did not reach the collective within 120 s (shared-memory communicator)", what);
+                return MCN_ERCCL;
+            }
+            sched_yield();
+        }
+    }
+    return MCN_OK;
+}
+
+static int shm_init(McnComm* mc, int numRanks, int rank, const char* name) {
+    ShmComm* c = new ShmComm;
+    c->rank = rank;
+    c->numRanks = numRanks;
+    c->slotBytes = kShmSlotBytes;
+    c->mapBytes = kShmHeaderBytes + (size_t)numRanks * c->slotBytes;
+    snprintf(c->name, sizeof(c->name), "%s", name);
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(c->name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd >= 0 && ftruncate(fd, (off_t)c->mapBytes) != 0) { close(fd); fd = -1; }
+    } else {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+        struct stat st;
+        while (true) {  // wait until rank 0 has created AND sized the segment
+            fd = shm_open(c->name, O_RDWR, 0600);
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= c->mapBytes) break;
+            if (fd >= 0) close(fd);
+            fd = -1;
+            if (std::chrono::steady_clock::now() > deadline) break;
+            usleep(2000);
+        }
+    }
+    if (fd < 0) {
+        mcn_set_error("shared-memory communicator: cannot open %s (rank %d): %s", c->name, rank, strerror(errno));
+        delete c;
+        return MCN_ERCCL;
+    }
+    void* m = mmap(nullptr, c->mapBytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        mcn_set_error("shared-memory communicator: mmap failed: %s", strerror(errno));
+        delete c;
+        return MCN_ERCCL;
+    }
+    c->hdr = (ShmHeader*)m;  // a fresh segment is zero-filled: arrived = generation = attached = 0
+    c->slots = (char*)m + kShmHeaderBytes;
+    if (rank == 0) {
+        c->hdr->numRanks = (uint32_t)numRanks;
+        c->hdr->slotBytes = c->slotBytes;
+    }
+    c->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+    while (c->hdr->attached.load(std::memory_order_acquire) < (uint32_t)numRanks) {
+        if (std::chrono::steady_clock::now() > deadline) {
+            mcn_set_error("shared-memory communicator: %u of %d ranks attached within 120 s", c->hdr->attached.load(), numRanks);
+            munmap(m, c->mapBytes);
+            if (rank == 0) shm_unlink(c->name);
+            delete c;
+            return MCN_ERCCL;
+        }
+        usleep(1000);
+    }
+    if (rank == 0) shm_unlink(c->name);  // everyone holds a mapping: the name can go
+    int rc = mcn_check_hip(hipHostMalloc((void**)&c->bounce, c->slotBytes, hipHostMallocDefault), "hipHostMalloc");
+    if (rc) return rc;
+    mc->shm = c;
+    return MCN_OK;
+}
+
+// one chunk of at most slotBytes: buf[0..n) <- sum over ranks (rank order) / recv <- concatenation
+static int shm_exchange(ShmComm* c, const float* send, float* recv, size_t n, bool gather, hipStream_t s, const char* what) {
+    int rc = mcn_check_hip(hipMemcpyAsync(c->slots + (size_t)c->rank * c->slotBytes, send, n * 4, hipMemcpyDeviceToHost, s), what);
+    if (!rc) rc = mcn_check_hip(hipStreamSynchronize(s), what);
+    if (rc) return rc;
+    if ((rc = shm_barrier(c, what))) return rc;
+    if (gather) {
+        for (int r = 0; r < c->numRanks && !rc; r++)
+            rc = mcn_check_hip(hipMemcpyAsync(recv + (size_t)r * n, c->slots + (size_t)r * c->slotBytes, n * 4, hipMemcpyHostToDevice, s), what);
+    } else {
+        const float* s0 = (const float*)c->slots;
+        for (size_t i = 0; i < n; i++) c->bounce[i] = s0[i];
+        for (int r = 1; r < c->numRanks; r++) {
+            const float* sr = (const float*)(c->slots + (size_t)r * c->slotBytes);
+            for (size_t i = 0; i < n; i++) c->bounce[i] += sr[i];
+        }
+        rc = mcn_check_hip(hipMemcpyAsync(recv, c->bounce, n * 4, hipMemcpyHostToDevice, s), what);
+    }
+    if (!rc) rc = mcn_check_hip(hipStreamSynchronize(s), what);
+    if (rc) return rc;
+    return shm_barrier(c, what);  // nobody overwrites a slot before every rank has read it
+}
+
 MCN_API int mcn_comm_unique_id(char idBytes[128]) {
+    const char* kind = getenv("MCN_COMM");
+    if (kind && strcmp(kind, "shm") == 0) {
+        memset(idBytes, 0, 128);
+        unsigned long long r = 0;
+        FILE* f = fopen("/dev/urandom", "rb");
+        if (f) { if (fread(&r, sizeof r, 1, f) != 1) r = 0; fclose(f); }
+        r ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        snprintf(idBytes, 128, "%s/mcn_%d_%016llx", kShmTag, (int)getpid(), r);
+        return MCN_OK;
+    }
     int rc = rccl_load();
     if (rc) return rc;
     rcclUniqueId id;
@@ -227,40 +377,78 @@ MCN_API int mcn_comm_unique_id(char idBytes[128]) {
 }
 
 MCN_API int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]) {
-    int rc = rccl_load();
-    if (rc) return rc;
-    rcclUniqueId id;
-    memcpy(id.internal, idBytes, 128);
-    rcclComm_t c = nullptr;
-    rc = rccl_check(g_rccl.CommInitRank(&c, numRanks, id, rank), "ncclCommInitRank");
-    *comm = c;
-    return rc;
+    MCN_REQUIRE(comm && idBytes && numRanks >= 1 && rank >= 0 && rank < numRanks, "mcn_comm_init: bad argument");
+    McnComm* mc = new McnComm;
+    int rc;
+    if (strncmp(idBytes, kShmTag, sizeof(kShmTag) - 1) == 0 && memchr(idBytes, 0, 128)) {
+        rc = shm_init(mc, numRanks, rank, idBytes + sizeof(kShmTag) - 1);
+    } else {
+        rc = rccl_load();
+        if (!rc) {
+            rcclUniqueId id;
+            memcpy(id.internal, idBytes, 128);
+            rc = rccl_check(g_rccl.CommInitRank(&mc->rccl, numRanks, id, rank), "ncclCommInitRank");
+        }
+    }
+    if (rc) {
+        delete mc;
+        *comm = nullptr;
+        return rc;
+    }
+    *comm = mc;
+    return MCN_OK;
 }
 
 MCN_API int mcn_comm_destroy(void* comm) {
-    if (!g_rccl.handle) return MCN_OK;
-    return rccl_check(g_rccl.CommDestroy((rcclComm_t)comm), "ncclCommDestroy");
+    McnComm* mc = (McnComm*)comm;
+    if (!mc) return MCN_OK;
+    int rc = MCN_OK;
+    if (mc->shm) {
+        if (mc->shm->bounce) (void)hipHostFree(mc->shm->bounce);
+        munmap(mc->shm->hdr, mc->shm->mapBytes);
+        delete mc->shm;
+    } else if (mc->rccl && g_rccl.handle) {
+        rc = rccl_check(g_rccl.CommDestroy(mc->rccl), "ncclCommDestroy");
+    }
+    delete mc;
+    return rc;
 }
 
 // ncclFloat32 = 7, ncclSum = 0 (rccl.h enums)
 MCN_API int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream) {
-    MCN_REQUIRE(g_rccl.handle && comm, "mcn_allreduce_sum: communicator not initialised");
-    return rccl_check(g_rccl.AllReduce(buf, buf, count, 7, 0, (rcclComm_t)comm, (hipStream_t)stream), "ncclAllReduce");
+    McnComm* mc = (McnComm*)comm;
+    MCN_REQUIRE(mc && buf, "mcn_allreduce_sum: communicator not initialised");
+    if (mc->shm) {
+        const size_t per = mc->shm->slotBytes / 4;
+        for (size_t off = 0; off < count; off += per)
+            if (int rc = shm_exchange(mc->shm, buf + off, buf + off, std::min(per, count - off), false, (hipStream_t)stream, "allreduce (shm)"))
+                return rc;
+        return MCN_OK;
+    }
+    MCN_REQUIRE(g_rccl.handle && mc->rccl, "mcn_allreduce_sum: communicator not initialised");
+    return rccl_check(g_rccl.AllReduce(buf, buf, count, 7, 0, mc->rccl, (hipStream_t)stream), "ncclAllReduce");
 }
 
 MCN_API int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream) {
-    MCN_REQUIRE(g_rccl.handle && comm, "mcn_allgather: communicator not initialised");
-    return rccl_check(g_rccl.AllGather(send, recv, countPerRank, 7, (rcclComm_t)comm, (hipStream_t)stream), "ncclAllGather");
+    McnComm* mc = (McnComm*)comm;
+    MCN_REQUIRE(mc && send && recv, "mcn_allgather: communicator not initialised");
+    if (mc->shm) {
+        MCN_REQUIRE(countPerRank * 4 <= mc->shm->slotBytes, "mcn_allgather: more than %zu bytes per rank (shared-memory communicator)",
+                    mc->shm->slotBytes);
+        return shm_exchange(mc->shm, send, recv, countPerRank, true, (hipStream_t)stream, "allgather (shm)");
+    }
+    MCN_REQUIRE(g_rccl.handle && mc->rccl, "mcn_allgather: communicator not initialised");
+    return rccl_check(g_rccl.AllGather(send, recv, countPerRank, 7, mc->rccl, (hipStream_t)stream), "ncclAllGather");
 }
 
 // collectives issued between the two calls are fused by RCCL into one launch
 MCN_API int mcn_comm_group_begin() {
-    MCN_REQUIRE(g_rccl.handle, "mcn_comm_group_begin: communicator not initialised");
+    if (!g_rccl.handle) return MCN_OK;  // shared-memory communicator: collectives run one by one, in the same order on every rank
     return rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
 }
 
 MCN_API int mcn_comm_group_end() {
-    MCN_REQUIRE(g_rccl.handle, "mcn_comm_group_end: communicator not initialised");
+    if (!g_rccl.handle) return MCN_OK;
     return rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
 }
 

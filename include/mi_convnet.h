@@ -496,7 +496,11 @@ int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, s
 int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream);
 
 /* ---- data-parallel exchange (no counterpart in the reference, which is single-GPU: convnet.py:52-53).
- * RCCL is loaded lazily; one communicator per process (one process per GPU). */
+ * RCCL is loaded lazily; one communicator per process (one process per GPU).
+ * With MCN_COMM=shm in the environment of the rank that calls mcn_comm_unique_id, the id names a POSIX shared-memory
+ * segment instead and the communicator stages every collective through it (fixed rank-order sums): a rehearsal
+ * transport for ranks that share ONE GPU, where RCCL refuses the second rank.  Same entry points, same results on
+ * every rank; not a production path. */
 int mcn_comm_unique_id(char idBytes[128]);
 int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]);
 int mcn_comm_destroy(void* comm);
