@@ -202,14 +202,20 @@ __global__ __launch_bounds__(256) void k_reduce_chunks(const float* __restrict__
     const int c = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < cols) {
-        int r = rg;
-        for (; r + 48 < chunks; r += 64) {
-            s0 += part[(size_t)r * cols + c];
-            s1 += part[(size_t)(r + 16) * cols + c];
-            s2 += part[(size_t)(r + 32) * cols + c];
-            s3 += part[(size_t)(r + 48) * cols + c];
+        // (60 blocks for conv1's 960 weights: a launch of pure latency.  All rows of a thread -- up to 32 per trip, conv1 has
+        // 468 strips = 30 -- are requested before the first add; four interleaved sums, rows in index order)
+        for (int r = rg; r < chunks; r += 512) {
+            float v[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) v[u] = r + 16 * u < chunks ? part[(size_t)(r + 16 * u) * cols + c] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 32; u += 4) {
+                s0 += v[u];
+                s1 += v[u + 1];
+                s2 += v[u + 2];
+                s3 += v[u + 3];
+            }
         }
-        for (; r < chunks; r += 16) s0 += part[(size_t)r * cols + c];
     }
     sh[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();

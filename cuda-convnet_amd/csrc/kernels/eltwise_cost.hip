@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
     softmax_merge16(reinterpret_cast<const f32x2*>(part), numCases, chunks, col, live, g, cl, shm, shs, M, S);
     if (!live) return;
     const int label = grad ? (int)labels[col] : -1;
+    const float rS = 1.0f / S;
     // a block normalises SMF_ROWS rows of its 16 columns, so that the merge above is repeated by few blocks
     const int r0 = chunk * SMF_ROWS;
     float v[SMF_ROWS / 16];
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
     for (int i = 0; i < SMF_ROWS / 16; i++) {
         const int r = r0 + g + 16 * i;
         if (r < numOut) {
-            const float pv = expf(v[i] - M) / S;
+            const float pv = expf(v[i] - M) * rS;
             p[(size_t)r * numCases + col] = pv;
             if (grad) grad[(size_t)r * numCases + col] = coeff * ((label == r ? 1.f : 0.f) - pv);
         }
@@ -464,90 +465,125 @@ struct LogregFuse {
     double* costOut;       // 2 accumulators
     int* tieCnt;           // (numCases) zero between calls
 };
-template <bool COST>
-__global__ __launch_bounds__(256) void k_softmax_final4(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
+// Merge (round 2, second form): the column maximum first -- fmax only: three xor-shuffles over the 8 lane groups of a wave,
+// the 4 waves through LDS -- then S = sum_c s_c * exp(m_c - M) with ONE exp per partial and plain adds in a fixed tree.
+// (The first form merged (m, s) pairs at every level: an exp per pair per level, and a serial 32-term tail on 32 threads
+// while the other 224 waited: 80 exp-equivalents on the critical wave against 40 here.)  All chunk partials of a thread are
+// requested in one batch next to its x values (<= SMF4_U batches of 32 chunks stay in registers: K <= 12288 rows; beyond
+// that the partials are read twice).  p = exp(x - M) * (1/S): the column's largest entry is exactly 1/S.
+#define SMF4_RES 192  // chunks whose partials stay in registers
+template <bool COST, int ROWS, int NW>
+__global__ __launch_bounds__(NW * 64) void k_softmax_final4(const float* __restrict__ x, float* __restrict__ p, const float* __restrict__ part,
                                                         int numOut, int numCases, int chunks, const float* __restrict__ labels,
                                                         float* __restrict__ grad, float coeff, LogregFuse lf) {
-    __shared__ float shm[32][33], shs[32][33], shM[32], shS[32];
-    const int cl = threadIdx.x & 7, g = threadIdx.x >> 3, col = blockIdx.x * 32 + 4 * cl;
+    constexpr int G = 8 * NW, SMF4_U = SMF4_RES / G;  // lane groups of 8 x 4 columns; chunk batches per group
+    __shared__ float shM[NW][32], shS[NW][32];
+    __shared__ int shc[NW][32];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cl = lane & 7, g = w * 8 + (lane >> 3), col = blockIdx.x * 32 + 4 * cl;
     const bool live = col < numCases;  // numCases % 4 == 0
     // this thread's x values first: their latency hides behind the merge of the partials
-    const int r0 = blockIdx.y * SMF4_ROWS;
-    f32x4 v[SMF4_ROWS / 32];
+    const int r0 = blockIdx.y * ROWS;
+    f32x4 v[ROWS / G];
 #pragma unroll
-    for (int i = 0; i < SMF4_ROWS / 32; i++) {
-        const int r = r0 + g + 32 * i;
+    for (int i = 0; i < ROWS / G; i++) {
+        const int r = r0 + g + G * i;
         v[i] = (live && r < numOut) ? *reinterpret_cast<const f32x4*>(x + (size_t)r * numCases + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // chunk partials of 4 consecutive columns = 8 consecutive floats (max, sum interleaved)
-    f32x4 lm = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, ls = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = g; c0 < chunks; c0 += 32 * 4) {
-        f32x4 v0[4], v1[4];
+    const f32x4 dead = {-INFINITY, 0.f, -INFINITY, 0.f};
+    const bool resident = chunks <= G * SMF4_U;
+    f32x4 pa[SMF4_U], pb[SMF4_U];
+    f32x4 M4 = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int c0 = g; c0 < chunks; c0 += G * SMF4_U) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int c = c0 + 32 * u;
+        for (int u = 0; u < SMF4_U; u++) {
+            const int c = c0 + G * u;
             const bool ok = live && c < chunks;
             const float* src = part + ((size_t)c * numCases + col) * 2;
-            v0[u] = ok ? *reinterpret_cast<const f32x4*>(src) : (f32x4){-INFINITY, 0.f, -INFINITY, 0.f};
-            v1[u] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : (f32x4){-INFINITY, 0.f, -INFINITY, 0.f};
+            pa[u] = ok ? *reinterpret_cast<const f32x4*>(src) : dead;
+            pb[u] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : dead;
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            float bm = lm[t];
-#pragma unroll
-            for (int u = 0; u < 4; u++) bm = fmaxf(bm, t < 2 ? v0[u][2 * t] : v1[u][2 * (t - 2)]);
-            float bs = lm[t] == -INFINITY ? 0.f : ls[t] * expf(lm[t] - bm);
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float m = t < 2 ? v0[u][2 * t] : v1[u][2 * (t - 2)], sv = t < 2 ? v0[u][2 * t + 1] : v1[u][2 * (t - 2) + 1];
-                bs += m == -INFINITY ? 0.f : sv * expf(m - bm);
-            }
-            lm[t] = bm;
-            ls[t] = bs;
+        for (int u = 0; u < SMF4_U; u++) {
+            M4[0] = fmaxf(M4[0], pa[u][0]);
+            M4[1] = fmaxf(M4[1], pa[u][2]);
+            M4[2] = fmaxf(M4[2], pb[u][0]);
+            M4[3] = fmaxf(M4[3], pb[u][2]);
         }
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        shm[g][4 * cl + t] = lm[t];
-        shs[g][4 * cl + t] = ls[t];
+        M4[t] = fmaxf(M4[t], __shfl_xor(M4[t], 8));
+        M4[t] = fmaxf(M4[t], __shfl_xor(M4[t], 16));
+        M4[t] = fmaxf(M4[t], __shfl_xor(M4[t], 32));
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) shM[w][4 * cl + t] = M4[t];
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int c = threadIdx.x;
-        float M = -INFINITY, S = 0.f;
 #pragma unroll
-        for (int k = 0; k < 32; k++) M = fmaxf(M, shm[k][c]);
+    for (int t = 0; t < 4; t++) {
+        M4[t] = shM[0][4 * cl + t];
 #pragma unroll
-        for (int k = 0; k < 32; k++) S += shm[k][c] == -INFINITY ? 0.f : shs[k][c] * expf(shm[k][c] - M);
-        shM[c] = M;
-        shS[c] = S;
+        for (int k = 1; k < NW; k++) M4[t] = fmaxf(M4[t], shM[k][4 * cl + t]);
+    }
+    f32x4 S4 = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = g; c0 < chunks; c0 += G * SMF4_U) {
+        if (!resident) {
+#pragma unroll
+            for (int u = 0; u < SMF4_U; u++) {
+                const int c = c0 + G * u;
+                const bool ok = live && c < chunks;
+                const float* src = part + ((size_t)c * numCases + col) * 2;
+                pa[u] = ok ? *reinterpret_cast<const f32x4*>(src) : dead;
+                pb[u] = ok ? *reinterpret_cast<const f32x4*>(src + 4) : dead;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SMF4_U; u++) {  // (m = -inf: an absent chunk, s = 0)
+            S4[0] += pa[u][0] == -INFINITY ? 0.f : pa[u][1] * expf(pa[u][0] - M4[0]);
+            S4[1] += pa[u][2] == -INFINITY ? 0.f : pa[u][3] * expf(pa[u][2] - M4[1]);
+            S4[2] += pb[u][0] == -INFINITY ? 0.f : pb[u][1] * expf(pb[u][0] - M4[2]);
+            S4[3] += pb[u][2] == -INFINITY ? 0.f : pb[u][3] * expf(pb[u][2] - M4[3]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        S4[t] += __shfl_xor(S4[t], 8);
+        S4[t] += __shfl_xor(S4[t], 16);
+        S4[t] += __shfl_xor(S4[t], 32);
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) shS[w][4 * cl + t] = S4[t];
     }
     __syncthreads();
     if (!COST && !live) return;
-    f32x4 M4, S4, pmax;
+    f32x4 rS;
     int lab[4], ties[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        M4[t] = shM[4 * cl + t];
-        S4[t] = shS[4 * cl + t];
+        S4[t] = (shS[0][4 * cl + t] + shS[1][4 * cl + t]) + (shS[2][4 * cl + t] + shS[3][4 * cl + t]);
+        if (NW == 8) S4[t] += (shS[4][4 * cl + t] + shS[5][4 * cl + t]) + (shS[6][4 * cl + t] + shS[7][4 * cl + t]);
+        rS[t] = 1.0f / S4[t];
         lab[t] = (labels && live) ? (int)labels[col + t] : -1;
-        pmax[t] = 1.0f / S4[t];
     }
     if (live) {
 #pragma unroll
-        for (int i = 0; i < SMF4_ROWS / 32; i++) {
-            const int r = r0 + g + 32 * i;
+        for (int i = 0; i < ROWS / G; i++) {
+            const int r = r0 + g + G * i;
             if (r < numOut) {
                 f32x4 pv, gv;
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    pv[t] = expf(v[i][t] - M4[t]) / S4[t];
+                    pv[t] = expf(v[i][t] - M4[t]) * rS[t];
                     gv[t] = coeff * ((lab[t] == r ? 1.f : 0.f) - pv[t]);
                     if (COST) {
-                        ties[t] += pv[t] == pmax[t] ? 1 : 0;
+                        ties[t] += pv[t] == rS[t] ? 1 : 0;
                         if (lab[t] == r) {
                             lf.labelLogProbs[col + t] = logf(pv[t]);
-                            lf.correctProbs[col + t] = pv[t] == pmax[t] ? 1.f : 0.f;
+                            lf.correctProbs[col + t] = pv[t] == rS[t] ? 1.f : 0.f;
                         }
                     }
                 }
@@ -557,16 +593,22 @@ __global__ __launch_bounds__(256) void k_softmax_final4(const float* __restrict_
         }
     }
     if (!COST) return;
-    // ---- logreg cost
-    int(*shc)[33] = reinterpret_cast<int(*)[33]>(shm);  // (every thread is past its reads of shm: shM / shS came after a barrier)
-    __syncthreads();
+    // ---- logreg cost: entries equal to the column's largest probability, counted per column (exact in any order)
 #pragma unroll
-    for (int t = 0; t < 4; t++) shc[g][4 * cl + t] = ties[t];
+    for (int t = 0; t < 4; t++) {
+        ties[t] += __shfl_xor(ties[t], 8);
+        ties[t] += __shfl_xor(ties[t], 16);
+        ties[t] += __shfl_xor(ties[t], 32);
+    }
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) shc[w][4 * cl + t] = ties[t];
+    }
     __syncthreads();
     if (threadIdx.x < 32) {
         int c = 0;
 #pragma unroll
-        for (int k = 0; k < 32; k++) c += shc[k][threadIdx.x];
+        for (int k = 0; k < NW; k++) c += shc[k][threadIdx.x];
         const int cc = blockIdx.x * 32 + threadIdx.x;
         if (c != 0 && cc < numCases) atomicAdd(&lf.tieCnt[cc], c);
     }
@@ -606,12 +648,18 @@ static bool softmax_final4_usable(const float* x, const float* probs, const floa
 }
 static int softmax_final_launch(const float* x, float* probs, const float* part, int numOut, int numCases, int chunks, const float* labels,
                                 float* grad, float coeff, hipStream_t s, const LogregFuse* lf = nullptr) {
+    static const int nwOpt = getenv("MCN_SOFTMAX_WAVES") ? atoi(getenv("MCN_SOFTMAX_WAVES")) : 4;
     const dim3 grid4(divup(numCases, 32), divup(numOut, SMF4_ROWS));
-    if (lf)  // (the caller has checked softmax_final4_usable)
-        hipLaunchKernelGGL((k_softmax_final4<true>), grid4, dim3(256), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, *lf);
-    else if (softmax_final4_usable(x, probs, part, grad, numOut, numCases))
-        hipLaunchKernelGGL((k_softmax_final4<false>), grid4, dim3(256), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff,
-                           LogregFuse{});
+#define SMF4_LAUNCH(COST, NW, LF) \
+    hipLaunchKernelGGL((k_softmax_final4<COST, SMF4_ROWS, NW>), grid4, dim3(NW * 64), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, LF)
+    if (lf) {  // (the caller has checked softmax_final4_usable)
+        if (nwOpt == 8) SMF4_LAUNCH(true, 8, *lf);
+        else SMF4_LAUNCH(true, 4, *lf);
+    } else if (softmax_final4_usable(x, probs, part, grad, numOut, numCases)) {
+        if (nwOpt == 8) SMF4_LAUNCH(false, 8, LogregFuse{});
+        else SMF4_LAUNCH(false, 4, LogregFuse{});
+    }
+#undef SMF4_LAUNCH
     else
         hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
                            numCases, chunks, labels, grad, coeff);

@@ -388,23 +388,38 @@ __global__ __launch_bounds__(256) void k_fc_tn_split(const FcParams p) {
     }
 }
 
-// slabs [splits][M*N] -> C = alpha * sum + beta * C; one 16-byte column group per thread, slabs added in index order,
-// eight loads in flight
+// slabs [splits][M*N] -> C = alpha * sum + beta * C.  The classifier's gradient is 160 x 128: one thread per 16-byte column
+// group would be 20 blocks and eight dependent round trips (5.6 us of pure latency).  Eight threads share a column group
+// instead: thread (o, g) adds the contiguous slab range g in index order with all its loads in flight, the eight ranges
+// meet in LDS and are added in a fixed tree -- 160 blocks, one round trip for up to 64 slabs.
 __global__ __launch_bounds__(256) void k_fc_tn_reduce(const FcParams p) {
+    __shared__ f32x4 sh[8][32];
     const size_t total4 = (size_t)p.M * p.N / 4;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.part) + i;
-    f32x4 s = src[0];
-    int z = 1;
-    for (; z + 7 < p.splits; z += 8) {
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + o;
+    const bool live = i < total4;
+    const int per = (p.splits + 7) / 8, z0 = g * per, z1 = min(p.splits, z0 + per);
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.part) + (live ? i : 0);
+    f32x4 s = F4ZERO;
+    int z = z0;
+    for (; z + 7 < z1; z += 8) {
         f32x4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) v[u] = src[(size_t)(z + u) * total4];
 #pragma unroll
         for (int u = 0; u < 8; u++) s += v[u];
     }
-    for (; z < p.splits; z++) s += src[(size_t)z * total4];
+    if (z < z1) {  // (the last range of 61 slabs holds 5)
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = z + u < z1 ? src[(size_t)(z + u) * total4] : F4ZERO;
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    sh[g][o] = s;
+    __syncthreads();
+    if (g != 0 || !live) return;
+    s = ((sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o])) + ((sh[4][o] + sh[5][o]) + (sh[6][o] + sh[7][o]));
     f32x4* c = reinterpret_cast<f32x4*>(p.C) + i;
     s = p.alpha * s;
     if (p.beta != 0.f) s += p.beta * *c;
@@ -491,7 +506,7 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     else hipLaunchKernelGGL((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
     int rc = MCN_LAUNCH_CHECK("gemm (fc tn)");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 256)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc tn reduce)");
 }
 

@@ -114,6 +114,8 @@ def main():
             cost = dev_double(2)
             call('mcn_gemm_bias_neuron_softmax_part', W, X, b, Y, O_, N, I, 0, 0.0, 0.0, part, nb, None)
             report(name + ' softmax+grad+cost', (lambda: call('mcn_softmax_logreg_cost', Y, probs, labels, grad, 1.0, O_, N, part, nb, ws, ws.nbytes, lp, cp, cost, state, sb, 1, None)), 4.0 * N * O_, 4.0 * 3 * N * O_)
+            report(name + ' softmax+grad+cost w/o finish', (lambda: call('mcn_softmax_logreg_cost', Y, probs, labels, grad, 1.0, O_, N, part, nb, ws, ws.nbytes, lp, cp, cost, state, sb, 0, None)), 4.0 * N * O_, 4.0 * 3 * N * O_)
+            call('mcn_softmax_logreg_cost_finish', lp, cp, cost, state, sb, N, None)
         report(name + ' bwd-weights (NT)', (lambda: call('mcn_gemm', dY, X, dW, O_, I, N, 0, 1, 0.001, 0.9, ws, ws.nbytes, None)), flops, nbytes)
 
 
