@@ -1531,6 +1531,7 @@ ConvNet::~ConvNet() {
     for (void* e : _bucketEvents) mcn_event_destroy(e);
     if (_gradStream) mcn_stream_destroy(_gradStream);
     for (void* e : _forkEvents) mcn_event_destroy(e);
+    if (_tickFlag) mcn_tick_free(_tickFlag);
     if (_evJoin) mcn_event_destroy(_evJoin);
     if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
@@ -1696,6 +1697,8 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
         chk(mcn_event_create_sync(&_evJoin), "event");
         _forkEvents.resize(32, nullptr);
         for (void*& e : _forkEvents) chk(mcn_event_create_sync(&e), "event");
+        // the side thread polls: forks are stream ticks (MCN_NO_TICKS=1: events, as before)
+        if (((g_hostWaitMask >> 1) & 1) && getenv("MCN_NO_TICKS") == nullptr) chk(mcn_tick_alloc(&_tickFlag), "tick flag");
         _side.start(_deviceID);
     }
     // this thread's backward-data products share the GPU with the side stream's weight gradients: the form that leaves
@@ -1984,12 +1987,36 @@ long ConvNet::forkSideWork(std::function<void()> fn) {
 
 // the first `count` deferred items become one task of the side thread, ordered after everything the main stream
 // holds at this point
+// The side thread waits until the main stream has run the tick kernel that flushSideWork queued (sequence numbers
+// increase, so a later tick covers an earlier one).  A main stream that dies never ticks: give up after a minute.
+void ConvNet::awaitTick(int tick) {
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile int* f = _tickFlag;
+    for (unsigned spin = 0; (int)(*f - tick) < 0; spin++) {
+        if ((spin & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+            throw NetError("the main stream did not reach a fork point within 60 s");
+    }
+    g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 void ConvNet::flushSideWork(size_t count) {
     if (count == 0) return;
-    void* forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
-    // (an event may be recorded again before the side thread has waited for its previous use: that wait then covers
-    // more of the main stream than it needs to, never less; 32 events make it rare)
-    chk(timedEventRecord(forkEvent, _stream), "event record");
+    const bool ticks = _tickFlag && !_capturing && !g_noHostWait;
+    void* forkEvent = nullptr;
+    int tick = 0;
+    if (ticks) {
+        // a one-thread kernel that writes a sequence number the side thread polls for: seen 5 us earlier than the event,
+        // and half the bubble on this stream (tools/event_poll_probe.hip)
+        tick = ++_tickSeq;
+        const auto t0 = std::chrono::steady_clock::now();
+        chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
+        g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
+        // (an event may be recorded again before the side thread has waited for its previous use: that wait then covers
+        // more of the main stream than it needs to, never less; 32 events make it rare)
+        chk(timedEventRecord(forkEvent, _stream), "event record");
+    }
     auto fns = std::make_shared<std::vector<std::function<void()>>>();
     for (size_t i = 0; i < count; i++) {
         fns->push_back(std::move(_deferred[i].first));
@@ -2011,9 +2038,10 @@ void ConvNet::flushSideWork(size_t count) {
         t_stream = 0;
         return;
     }
-    _side.push([this, forkEvent, fns] {
+    _side.push([this, forkEvent, tick, fns] {
         t_stream = 1;
-        chk(timedStreamWait(_gradStream, forkEvent), "wait event");
+        if (forkEvent) chk(timedStreamWait(_gradStream, forkEvent), "wait event");
+        else awaitTick(tick);
         for (auto& fn : *fns) fn();
     });
 }

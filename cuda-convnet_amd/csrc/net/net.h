@@ -782,6 +782,9 @@ class ConvNet {
     Uploader _uploader;
     std::vector<void*> _forkEvents;
     size_t _forkNext = 0;
+    int* _tickFlag = nullptr;  // main stream -> side thread forks as stream ticks (mcn_stream_tick) instead of events
+    int _tickSeq = 0;
+    void awaitTick(int tick);
     std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread
     std::vector<void*> _bucketEvents;  // ring: producer-side records for the exchange thread to wait on
     size_t _bucketNext = 0;

@@ -82,6 +82,14 @@ int mcn_stream_wait_event(void* stream, void* event);
 int mcn_event_query(void* event);
 int mcn_event_elapsed_ms(float* ms, void* start, void* stop);
 
+/* Stream ticks (no counterpart in the reference): mcn_stream_tick queues a one-thread kernel that stores `value` into
+ * `flag`, 64 bytes of host-visible coherent memory from mcn_tick_alloc.  A host thread that polls *flag learns that the
+ * stream has passed this point ~5 us before mcn_event_query reports an event recorded at the same place, and the stream
+ * loses 1.5 us instead of 3 us (tools/event_poll_probe.hip).  Values should increase; compare with (int)(*flag - value) >= 0. */
+int mcn_tick_alloc(int** flag);
+int mcn_tick_free(int* flag);
+int mcn_stream_tick(int* flag, int value, void* stream);
+
 /* Step graphs (no counterpart in the reference, whose step is ~45 launches and several blocking copies per minibatch):
  * everything issued on `stream`, and on streams that join it through events, between begin and end is captured into one
  * executable graph (nothing runs during capture); mcn_graph_launch replays it on a stream.  numNodes may be NULL. */
