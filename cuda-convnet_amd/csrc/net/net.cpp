@@ -1532,6 +1532,7 @@ ConvNet::~ConvNet() {
     if (_gradStream) mcn_stream_destroy(_gradStream);
     for (void* e : _forkEvents) mcn_event_destroy(e);
     if (_tickFlag) mcn_tick_free(_tickFlag);
+    if (_tickFlagSide) mcn_tick_free(_tickFlagSide);
     if (_evJoin) mcn_event_destroy(_evJoin);
     if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
@@ -1698,7 +1699,13 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
         _forkEvents.resize(32, nullptr);
         for (void*& e : _forkEvents) chk(mcn_event_create_sync(&e), "event");
         // the side thread polls: forks are stream ticks (MCN_NO_TICKS=1: events, as before)
-        if (((g_hostWaitMask >> 1) & 1) && getenv("MCN_NO_TICKS") == nullptr) chk(mcn_tick_alloc(&_tickFlag), "tick flag");
+        if (((g_hostWaitMask >> 1) & 1) && getenv("MCN_NO_TICKS") == nullptr) {
+            chk(mcn_tick_alloc(&_tickFlag), "tick flag");
+            chk(mcn_tick_alloc(&_tickFlagSide), "tick flag");
+            // the exchange thread too (MCN_COMM_TICKS=1).  MEASURED, forced data-parallel step with one rank: 0.328 ms with,
+            // 0.325 ms without -- its waits are few and the collectives behind them long; opt-in
+            _commTicks = getenv("MCN_COMM_TICKS") != nullptr;
+        }
         _side.start(_deviceID);
     }
     // this thread's backward-data products share the GPU with the side stream's weight gradients: the form that leaves
@@ -1989,19 +1996,19 @@ long ConvNet::forkSideWork(std::function<void()> fn) {
 // holds at this point
 // The side thread waits until the main stream has run the tick kernel that flushSideWork queued (sequence numbers
 // increase, so a later tick covers an earlier one).  A main stream that dies never ticks: give up after a minute.
-void ConvNet::awaitTick(int tick) {
+void ConvNet::awaitTick(int tick, volatile int* flag) {
     const auto t0 = std::chrono::steady_clock::now();
-    volatile int* f = _tickFlag;
+    volatile int* f = flag ? flag : _tickFlag;
     for (unsigned spin = 0; (int)(*f - tick) < 0; spin++) {
         if ((spin & 0xfffff) == 0xfffff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
-            throw NetError("the main stream did not reach a fork point within 60 s");
+            throw NetError("a stream did not reach a fork point within 60 s");
     }
     g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 void ConvNet::flushSideWork(size_t count) {
     if (count == 0) return;
-    const bool ticks = _tickFlag && !_capturing && !g_noHostWait;
+    const bool ticks = _tickFlag && !_capturing && !g_noHostWait && t_stream == 0;  // (only the thread that feeds a stream ticks it)
     void* forkEvent = nullptr;
     int tick = 0;
     if (ticks) {
@@ -2050,9 +2057,18 @@ void ConvNet::flushSideWork(size_t count) {
 // all-gather, margin search and cost in ONE hop to one thread -- through the side thread it took three hops and kept
 // that thread from issuing the gradients of fc6 / fc5).
 long ConvNet::forkExchangeWork(std::function<void()> fn) {
+    _exchangeWorkPending = true;
+    if (_commTicks && !_capturing && !g_noHostWait && t_stream == 0) {
+        const int tick = ++_tickSeq;
+        chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
+        return _commSub.push([this, tick, fn] {
+            t_stream = 2;
+            awaitTick(tick, _tickFlag);
+            fn();
+        });
+    }
     void* forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
     chk(timedEventRecord(forkEvent, _stream), "event record");
-    _exchangeWorkPending = true;
     return _commSub.push([this, forkEvent, fn] {
         t_stream = 2;
         chk(timedStreamWait(_commStream, forkEvent), "wait event");
@@ -2318,19 +2334,35 @@ void ConvNet::flushBuckets(bool force) {
     // the producer records (cheap), the exchange thread waits and calls RCCL (expensive)
     void* evMain = nullptr;
     void* evSide = nullptr;
+    // (a stream's ticks must be queued in increasing order: only the thread that feeds a stream ticks it, anyone else
+    // records an event -- the side thread sends side-stream buckets, the main thread the forced rest, so that is rare)
+    int tickMain = 0, tickSide = 0;
+    const bool ticks = _commTicks && !_capturing && !g_noHostWait;
     if (onMain) {
-        evMain = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
-        chk(timedEventRecord(evMain, _stream), "event record");
+        if (ticks && t_stream == 0) {
+            tickMain = ++_tickSeq;
+            chk(mcn_stream_tick(_tickFlag, tickMain, _stream), "stream tick");
+        } else {
+            evMain = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
+            chk(timedEventRecord(evMain, _stream), "event record");
+        }
     }
     if (onSide) {
-        evSide = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
-        chk(timedEventRecord(evSide, _gradStream), "event record");
+        if (ticks && t_stream == 1) {
+            tickSide = ++_tickSeqSide;
+            chk(mcn_stream_tick(_tickFlagSide, tickSide, _gradStream), "stream tick");
+        } else {
+            evSide = _bucketEvents[_bucketNext++ % _bucketEvents.size()];
+            chk(timedEventRecord(evSide, _gradStream), "event record");
+        }
     }
     float* buf = _gradArena.p + _sentUpTo;
     const size_t count = end - _sentUpTo;
-    _commSub.push([this, evMain, evSide, buf, count] {
+    _commSub.push([this, evMain, evSide, tickMain, tickSide, buf, count] {
         if (evMain) chk(timedStreamWait(_commStream, evMain), "wait event");
         if (evSide) chk(timedStreamWait(_commStream, evSide), "wait event");
+        if (tickMain) awaitTick(tickMain, _tickFlag);
+        if (tickSide) awaitTick(tickSide, _tickFlagSide);
         const auto t0 = std::chrono::steady_clock::now();
         chk(mcn_allreduce_sum(_comm, buf, count, _commStream), "all-reduce");
         logComm(0, (size_t)(buf - _gradArena.p), count);

@@ -784,7 +784,10 @@ class ConvNet {
     size_t _forkNext = 0;
     int* _tickFlag = nullptr;  // main stream -> side thread forks as stream ticks (mcn_stream_tick) instead of events
     int _tickSeq = 0;
-    void awaitTick(int tick);
+    int* _tickFlagSide = nullptr;  // side stream -> exchange thread (gradient buckets written by the side stream)
+    int _tickSeqSide = 0;
+    bool _commTicks = false;       // the exchange thread polls ticks instead of queueing event waits
+    void awaitTick(int tick, volatile int* flag = nullptr);
     std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread
     std::vector<void*> _bucketEvents;  // ring: producer-side records for the exchange thread to wait on
     size_t _bucketNext = 0;
