@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, 'libmiconvnet.so')
 _CTYPES = {
     'int': C.c_int, 'float': C.c_float, 'size_t': C.c_size_t, 'void*': C.c_void_p, 'void**': C.POINTER(C.c_void_p),
     'const void*': C.c_void_p, 'float*': C.c_void_p, 'const float*': C.c_void_p, 'double*': C.c_void_p,
-    'int*': C.POINTER(C.c_int), 'const int*': C.c_void_p, 'const float* const*': C.c_void_p, 'float* const*': C.c_void_p, 'const mcn_sgd_item*': C.c_void_p, 'const mcn_row_sum_item*': C.c_void_p, 'char*': C.c_char_p, 'const char*': C.c_char_p,
+    'int*': C.POINTER(C.c_int), 'int**': C.POINTER(C.c_void_p), 'const int*': C.c_void_p, 'const float* const*': C.c_void_p, 'float* const*': C.c_void_p, 'const mcn_sgd_item*': C.c_void_p, 'const mcn_row_sum_item*': C.c_void_p, 'char*': C.c_char_p, 'const char*': C.c_char_p,
 }
 
 

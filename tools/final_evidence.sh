@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
+if [ "$1" != "rest" ]; then
 timeout -k 10 400 python -u bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 1; }
 echo "bench done"
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-profile > $O/prof.log 2>&1) || { tail -5 $O/prof.log; exit 1; }
@@ -18,6 +19,7 @@ cp "$S" $O/kernel_stats.csv && python tools/step_timeline.py "$T" 60 > $O/step_t
 rm -rf $O/prof
 timeout -k 10 200 python tools/phases.py > $O/phases.txt 2>&1 || { tail -5 $O/phases.txt; exit 1; }
 echo "phases done"
+fi
 timeout -k 10 400 python tools/kbench.py > $O/kbench.txt 2>&1 || { tail -5 $O/kbench.txt; exit 1; }
 echo "kbench done"
 timeout -k 10 300 python -u bench.py --workload deepid2plus --no-cpu-baseline > $O/bench_deepid2plus.json 2>> $O/bench.err || exit 1
