@@ -24,6 +24,18 @@ int mcn_check_hip(hipError_t e, const char* what);
 int mcn_launch_check(const char* what);  // hipGetLastError + this thread's launch counter (mcn_launch_count)
 #define MCN_LAUNCH_CHECK(name) mcn_launch_check(name)
 
+// A tick armed by mcn_arm_tick for this thread's next launch on `stream`: a kernel that supports it takes (flag, value) into
+// its parameter block and stores value into *flag in its first instructions (MCN_TICK_PROLOGUE) -- a kernel only starts when
+// everything queued before it on its stream has finished.  Any other launch leaves the tick armed and mcn_launch_check sends it
+// with a one-thread kernel right behind that launch.
+struct McnTick {
+    int* flag;
+    int value;
+};
+McnTick mcn_take_tick(hipStream_t stream);  // {nullptr, 0} when nothing is armed for that stream
+#define MCN_TICK_PROLOGUE(p)                                                                                          \
+    if ((p).tick.flag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) *(volatile int*)(p).tick.flag = (p).tick.value
+
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline size_t divup_sz(size_t a, size_t b) { return (a + b - 1) / b; }
 

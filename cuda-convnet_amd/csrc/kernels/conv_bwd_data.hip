@@ -26,6 +26,7 @@ struct BwdDataParams {
     float* uTarget;      // gradient w.r.t. the pool's input
     int uNeuron;         // >= 0: times the gradient of the neuron that produced uActs
     float uNa, uNb;
+    McnTick tick;        // stored by the launch's first thread (MCN_TICK_PROLOGUE)
 };
 
 // A step = one (module, 16 filters) pair.  The steps a pixel needs are walked in batches of U: the loads of the
@@ -40,6 +41,7 @@ struct BwdDataParams {
 // unrolled epilogue grew to 28 k instructions and the launch lost more in instruction fetch than the fusion saved)
 template <int CV, int NQ, bool VECN, int U, int KS = 1, int UNDO = 0>
 __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
+    MCN_TICK_PROLOGUE(p);
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
     const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
@@ -346,6 +348,7 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     p.N = N; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs; p.mY = mY; p.mX = mX;
     p.pad = pad; p.stride = stride; p.groups = groups; p.conv = conv; p.sT = sT; p.sO = sO;
     p.uActs = nullptr; p.uMax = nullptr; p.uTarget = nullptr; p.uNeuron = -1; p.uNa = p.uNb = 0.f;
+    p.tick = {nullptr, 0};
     const int fc = C / groups, imgPixels = imgY * imgX;
     const bool vecn = (N % 4 == 0) && (((uintptr_t)hidActs | (uintptr_t)targets) % 16 == 0);
     if (undo) {
@@ -365,6 +368,7 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     dim3 grid(divup(N, 64 * NQ), divup(imgPixels, 4), groups * divup(fc, 16 * CV));
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "imgActs: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    p.tick = mcn_take_tick(s);
     // few waves per SIMD and few steps per pixel: the launch is bound by each wave's chain of memory round trips ->
     // batched, prefetched steps (measured: local3 18.8 -> 15.6 us; long step chains and shared-weight layers do not gain)
     const int maxSteps = divup(fs, stride) * divup(fs, stride) * (F / groups / 16);

@@ -21,12 +21,14 @@ struct BwdWParams {
     int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups;
     int modulesPerChunk, check;
     float sT, sO;
+    McnTick tick;  // stored by the launch's first thread (MCN_TICK_PROLOGUE)
 };
 
 // MODE 0: scalar loads (any N / alignment); 1: 16-byte loads through pointers; 2: 16-byte buffer loads -- lanes outside
 // the matrix get an out-of-range offset and read zero, so the loop body has no branches (buffers below 2 GB).
 template <int KV, int FV, int MODE>
 __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
+    MCN_TICK_PROLOGUE(p);
     constexpr bool VECN = MODE >= 1;
     extern __shared__ int tbl[];
     const int fc = p.C / p.groups, fpg = p.F / p.groups, fp = p.fs * p.fs;
@@ -262,6 +264,7 @@ static int weight_acts_launch(const float* images, const float* hidActs, float* 
     p.N = N; p.imgStride = imgStride; p.imgY = imgY; p.imgX = imgX; p.C = C; p.F = F; p.fs = fs;
     p.mY = mY; p.mX = mX; p.pad = pad; p.stride = stride; p.groups = groups;
     p.modulesPerChunk = modulesPerChunk; p.sT = sT; p.sO = sO;
+    p.tick = {nullptr, 0};
     const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
     p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY);
     const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)hidActs) % 16 == 0);
@@ -279,6 +282,7 @@ static int weight_acts_launch(const float* images, const float* hidActs, float* 
     size_t lds = (size_t)ktiles * 16 * KV * 8;  // decode table, reused for the cross-wave reduction
     if (lds < (size_t)KV * FV * 64 * 16) lds = (size_t)KV * FV * 64 * 16;
     MCN_REQUIRE(lds <= 64 * 1024, "weightActs: filter too large for the decode table (%zu bytes)", lds);
+    p.tick = mcn_take_tick(s);
     if (KV == 3 && FV == 2) launch_bw2<3, 2>(p, grid, lds, vecn, s);
     else if (KV == 3) launch_bw2<3, 1>(p, grid, lds, vecn, s);
     else if (KV == 2 && FV == 2) launch_bw2<2, 2>(p, grid, lds, vecn, s);
@@ -331,11 +335,13 @@ struct StripParams {
     int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride;
     int MS, CB, W, stripsPerRow;
     float sO;
+    McnTick tick;  // stored by the launch's first thread (MCN_TICK_PROLOGUE)
 };
 
 template <int KT, int FV>
 __global__ __launch_bounds__(256) void k_conv_wgrad_strip(const StripParams p) {
     extern __shared__ float lds[];
+    MCN_TICK_PROLOGUE(p);
     constexpr int RS = 36;     // floats per LDS row: 32 images + 4 of padding (bank spread)
     constexpr int PI = 8;      // image-row load passes (32 rows each) a thread can hold
     constexpr int PH = 4 * FV; // gradient-row load passes (MS <= 8)
@@ -547,6 +553,7 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
         dim3 grid(pl.strips, numImgColors / pl.CB, numFilters / (16 * pl.FV));
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "convWeightActsReduced: grid too large");
         hipStream_t s = (hipStream_t)stream;
+        sp.tick = mcn_take_tick(s);
         switch (pl.KT) {
             case 1: launch_strip<1>(sp, pl, grid, s); break;
             case 2: launch_strip<2>(sp, pl, grid, s); break;

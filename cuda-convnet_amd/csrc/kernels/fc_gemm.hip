@@ -31,6 +31,7 @@ struct FcParams {
     int kChunk, splits;
     int neuron;
     float alpha, beta, na, nb;
+    McnTick tick;    // NN / TN split: stored by the launch's first thread (MCN_TICK_PROLOGUE)
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -45,6 +46,7 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 template <int S>
 __global__ __launch_bounds__(256) void k_fc_nn_lds(const FcParams p) {
     extern __shared__ f32x4 lds4[];
+    MCN_TICK_PROLOGUE(p);
     float* lds = reinterpret_cast<float*>(lds4);
     constexpr int KC = 16 * S, NLD = KC * 32 / 256;  // staging loads (16 B) per thread and chunk
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(256) void k_fc_nt_lds(const FcParams p) {
 template <int MG, int U>
 __global__ __launch_bounds__(256) void k_fc_tn_split(const FcParams p) {
     extern __shared__ f32x4 red[];
+    MCN_TICK_PROLOGUE(p);
     constexpr int H = MG / 4, R = MG % 4, T = MG * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
@@ -460,6 +463,7 @@ static FcParams fc_params(const float* A, const float* B, const float* bias, flo
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.smPart = nullptr; p.part = nullptr;
     p.M = M; p.N = N; p.K = K; p.kChunk = K; p.splits = 1;
     p.neuron = neuron; p.alpha = alpha; p.beta = beta; p.na = na; p.nb = nb;
+    p.tick = {nullptr, 0};
     return p;
 }
 
@@ -469,6 +473,7 @@ int fc_nn_lds_launch(const float* A, const float* B, const float* bias, float* C
     p.smPart = smPart;
     dim3 grid(divup(M, 64), divup(N, 128));
     MCN_REQUIRE(grid.y <= 65535, "gemm: grid too large");
+    p.tick = mcn_take_tick(s);  // (after the last check: a tick taken is a tick sent)
     // 160-row chunks when they waste nothing (K = 160), else 128
     if (K % 160 == 0 || (K < 160 && K > 128)) hipLaunchKernelGGL((k_fc_nn_lds<10>), grid, dim3(256), 160 * 128 * 4, s, p);
     else hipLaunchKernelGGL((k_fc_nn_lds<8>), grid, dim3(256), 128 * 128 * 4, s, p);
@@ -502,6 +507,7 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     p.splits = pl.splits;
     dim3 grid(divup(N, 64), divup(M, 16 * pl.mg), pl.splits);
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+    p.tick = mcn_take_tick(s);
     if (pl.mg == 5) hipLaunchKernelGGL((k_fc_tn_split<5, 6>), grid, dim3(256), 2 * 20 * 64 * 16, s, p);
     else hipLaunchKernelGGL((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
     int rc = MCN_LAUNCH_CHECK("gemm (fc tn)");
@@ -533,6 +539,7 @@ struct FcMultiParams {
     int M, N, Kb;                 // forward: M, N;  backward: Kb = K (outputs of the layer), N
     int neuron;
     float fa, fb, fbeta;
+    McnTick tick;                 // backward-data: stored by the launch's first thread (MCN_TICK_PROLOGUE)
 };
 
 // ---- forward: Y[M x N] = sum_i W_i X_i (+ bias, neuron).  One workgroup of 8 waves per 16 x 16 tile of Y; the waves split the
@@ -614,6 +621,7 @@ __global__ __launch_bounds__(512) void k_fc_fprop_multi(const FcMultiParams p) {
 // U, no LDS, no barrier.  Optional epilogue: the gradient of the neuron that produced X_i, from its output.
 template <int U>
 __global__ __launch_bounds__(64) void k_fc_bprop_multi(const FcMultiParams p) {
+    MCN_TICK_PROLOGUE(p);
     const int lane = threadIdx.x, kk = lane >> 4, j = lane & 15;
     int seg = 0, tile = blockIdx.y;
     while (tile >= p.steps[seg]) { tile -= p.steps[seg]; seg++; }
@@ -744,6 +752,7 @@ int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi
     for (int i = count; i < FCM_MAXSEG; i++) p.steps[i] = 1 << 30;
     p.dY = dY; p.Kb = K; p.N = N;
     dim3 grid(divup(N, 32), tiles);
+    p.tick = mcn_take_tick(s);
     hipLaunchKernelGGL((k_fc_bprop_multi<10>), grid, dim3(64), 0, s, p);
     return MCN_LAUNCH_CHECK("fcBpropActsMulti");
 }

@@ -29,9 +29,31 @@ int mcn_check_hip(hipError_t e, const char* what) {
     return MCN_EHIP;
 }
 
+static thread_local struct {
+    int* flag = nullptr;
+    int value = 0;
+    hipStream_t stream = nullptr;
+} t_tick;
+__global__ void k_stream_tick(volatile int* flag, int value);
+static void tick_send_now() {
+    if (!t_tick.flag) return;
+    hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value);
+    t_tick.flag = nullptr;
+}
+McnTick mcn_take_tick(hipStream_t stream) {
+    McnTick t = {nullptr, 0};
+    if (t_tick.flag && t_tick.stream == stream) {
+        t.flag = t_tick.flag;
+        t.value = t_tick.value;
+        t_tick.flag = nullptr;
+    }
+    return t;
+}
+
 static thread_local size_t t_launches = 0;
 int mcn_launch_check(const char* what) {
     t_launches++;
+    tick_send_now();  // (a tick the launch above did not carry: right behind it)
     // MCN_LAUNCH_DELAY_NS (diagnostic): busy-wait after every launch -- if a step slows down by launches x delay the step
     // is bound by the submitting threads, if it does not the device is
     static const long delayNs = getenv("MCN_LAUNCH_DELAY_NS") ? atol(getenv("MCN_LAUNCH_DELAY_NS")) : 0;
@@ -177,6 +199,21 @@ MCN_API int mcn_graph_destroy(void* graphExec) {
 // back, 255 us with a tick after each, 285 us with an event after each).
 // ---------------------------------------------------------------------------
 __global__ void k_stream_tick(volatile int* flag, int value) { *flag = value; }
+// The tick rides on this thread's NEXT launch: in the first instructions of a kernel that has a tick slot (the classifier
+// products, the multi-input backward-data product, imgActs, the strip weight gradient), else in a one-thread kernel behind
+// it.  mcn_flush_tick sends an armed tick at once (before the caller blocks on whoever waits for it).
+MCN_API int mcn_arm_tick(int* flag, int value, void* stream) {
+    MCN_REQUIRE(flag, "armTick: null pointer");
+    tick_send_now();  // (an older one first: ticks of a stream stay in order)
+    t_tick.flag = flag;
+    t_tick.value = value;
+    t_tick.stream = (hipStream_t)stream;
+    return MCN_OK;
+}
+MCN_API int mcn_flush_tick(void) {
+    tick_send_now();
+    return mcn_check_hip(hipGetLastError(), "flushTick");
+}
 MCN_API int mcn_tick_alloc(int** flag) {
     MCN_REQUIRE(flag, "tickAlloc: null pointer");
     int rc = mcn_check_hip(hipHostMalloc((void**)flag, 64, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc (tick)");
@@ -186,6 +223,7 @@ MCN_API int mcn_tick_alloc(int** flag) {
 MCN_API int mcn_tick_free(int* flag) { return flag ? mcn_check_hip(hipHostFree(flag), "hipHostFree (tick)") : MCN_OK; }
 MCN_API int mcn_stream_tick(int* flag, int value, void* stream) {
     MCN_REQUIRE(flag, "streamTick: null pointer");
+    tick_send_now();  // (an armed one first: ticks stay in order)
     hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value);
     return mcn_check_hip(hipGetLastError(), "streamTick");
 }

@@ -1642,6 +1642,7 @@ void ConvNet::run() {  // convnet.cu:147-156
 // a data-parallel replica: it has skipped collectives its peers are blocked in, so it refuses further work and the
 // launcher has to tear the group down.
 void ConvNet::resetAfterError() {
+    mcn_flush_tick();  // (a fork whose tick no launch has carried yet: the side thread is waiting for it)
     auto drain = [](Submitter& s) {
         if (!s.running()) return;
         try {
@@ -1874,7 +1875,10 @@ void Submitter::wait(long ticket) {
 }
 
 void ConvNet::waitSideSubmitted(long ticket) {
-    if (ticket > 0) _side.wait(ticket);
+    if (ticket > 0) {
+        chk(mcn_flush_tick(), "flush tick");  // (the side thread may be waiting for a tick that no launch has carried yet)
+        _side.wait(ticket);
+    }
 }
 
 // Bias gradients: row sums over 0.1-19 MB, one or two launches of 2-5 us per layer (eight per DeepID2 step, ~30 us of the
@@ -2014,9 +2018,14 @@ void ConvNet::flushSideWork(size_t count) {
     if (ticks) {
         // a one-thread kernel that writes a sequence number the side thread polls for: seen 5 us earlier than the event,
         // and half the bubble on this stream (tools/event_poll_probe.hip)
+        // ... carried by this thread's next launch: in the first instructions of the kernel itself where it has a tick slot
+        // (the backward-data kernels that follow a weight layer's fork all do), else in a kernel of its own behind it
+        // (MCN_TICK_KERNEL=1: always a kernel of its own, at once)
         tick = ++_tickSeq;
+        static const bool ownKernel = getenv("MCN_TICK_KERNEL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
+        if (ownKernel) chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
+        else chk(mcn_arm_tick(_tickFlag, tick, _stream), "arm tick");
         g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     } else {
         forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
@@ -2160,7 +2169,10 @@ void ConvNet::joinGradWork() {
     runLateWork();
     joinExchange();
     if (!_gradPending) return;
-    if (!_capturing) _side.wait(_side.pushed());  // the side thread has issued everything it was given
+    if (!_capturing) {
+        chk(mcn_flush_tick(), "flush tick");  // (as in waitSideSubmitted)
+        _side.wait(_side.pushed());  // the side thread has issued everything it was given
+    }
     chk(timedEventRecord(_evJoin, _gradStream), "event record");
     chk(timedStreamWait(_stream, _evJoin), "wait event");
     _gradPending = false;

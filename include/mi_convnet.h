@@ -89,6 +89,13 @@ int mcn_event_elapsed_ms(float* ms, void* start, void* stop);
 int mcn_tick_alloc(int** flag);
 int mcn_tick_free(int* flag);
 int mcn_stream_tick(int* flag, int value, void* stream);
+/* The same tick carried by the calling thread's NEXT launch on `stream` instead of a kernel of its own: kernels with a tick
+ * slot (mcn_gemm's classifier forms, mcn_fc_bprop_acts_multi, the imgActs family, the strip form of
+ * mcn_conv_weight_acts_reduced) store the value in their first instructions -- a kernel starts only when everything queued
+ * before it on its stream has finished -- and any other launch is followed by a one-thread tick kernel.  mcn_flush_tick sends
+ * an armed tick at once; call it before blocking on whoever polls for it. */
+int mcn_arm_tick(int* flag, int value, void* stream);
+int mcn_flush_tick(void);
 
 /* Step graphs (no counterpart in the reference, whose step is ~45 launches and several blocking copies per minibatch):
  * everything issued on `stream`, and on streams that join it through events, between begin and end is captured into one
