@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void k_softmax_final(const float* __restrict__
         }
     }
 }
-// The same stage 2 with 16-byte accesses: a block owns 32 columns (8 lanes x 4) x SMF4_ROWS rows, so that every wave
+// The same stage 2 with 16-byte accesses: a block of NW waves owns 32 columns (8 lanes x 4) x ROWS rows (256 rows and 8 waves
+// as launched: measured 8.6 us against 9.4 us for 128 x 8, 9.3 for 128 x 4, 10.8 for 256 x 4, 11.0 for 512 x 8), so that every wave
 // instruction touches whole 128-byte lines of x / p / grad (the scalar form above moves 64 bytes per row and lane group).
 // Merge: lane group g (of 32) merges chunks g, g+32, ... of its 4 columns, the 32 groups are combined through LDS by 32
 // threads (one column each, fixed order) and M, S are broadcast through LDS.
@@ -644,21 +645,28 @@ __global__ __launch_bounds__(256) void k_logreg_finish(LogregFuse lf, int numCas
     }
 }
 static bool softmax_final4_usable(const float* x, const float* probs, const float* part, const float* grad, int numOut, int numCases) {
-    return numCases % 4 == 0 && al16(x) && al16(probs) && al16(part) && (!grad || al16(grad)) && divup(numOut, SMF4_ROWS) <= 65535;
+    return numCases % 4 == 0 && al16(x) && al16(probs) && al16(part) && (!grad || al16(grad)) && divup(numOut, 128) <= 65535;
 }
 static int softmax_final_launch(const float* x, float* probs, const float* part, int numOut, int numCases, int chunks, const float* labels,
                                 float* grad, float coeff, hipStream_t s, const LogregFuse* lf = nullptr) {
-    static const int nwOpt = getenv("MCN_SOFTMAX_WAVES") ? atoi(getenv("MCN_SOFTMAX_WAVES")) : 4;
-    const dim3 grid4(divup(numCases, 32), divup(numOut, SMF4_ROWS));
-#define SMF4_LAUNCH(COST, NW, LF) \
-    hipLaunchKernelGGL((k_softmax_final4<COST, SMF4_ROWS, NW>), grid4, dim3(NW * 64), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, LF)
+    static const int nwOpt = getenv("MCN_SOFTMAX_WAVES") ? atoi(getenv("MCN_SOFTMAX_WAVES")) : 8;
+    static const int rowsOpt = getenv("MCN_SOFTMAX_ROWS") ? atoi(getenv("MCN_SOFTMAX_ROWS")) : 256;
+    const int rows = rowsOpt == 512 ? 512 : rowsOpt == 128 ? 128 : 256, nw = nwOpt == 4 ? 4 : 8;
+    const dim3 grid4(divup(numCases, 32), divup(numOut, rows));
+#define SMF4_LAUNCH(COST, ROWS, NW, LF) \
+    hipLaunchKernelGGL((k_softmax_final4<COST, ROWS, NW>), grid4, dim3(NW * 64), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, LF)
+#define SMF4_PICK(COST, LF)                                     \
+    if (rows == 512) SMF4_LAUNCH(COST, 512, 8, LF);             \
+    else if (rows == 256 && nw == 8) SMF4_LAUNCH(COST, 256, 8, LF); \
+    else if (rows == 256) SMF4_LAUNCH(COST, 256, 4, LF);        \
+    else if (nw == 8) SMF4_LAUNCH(COST, 128, 8, LF);            \
+    else SMF4_LAUNCH(COST, 128, 4, LF)
     if (lf) {  // (the caller has checked softmax_final4_usable)
-        if (nwOpt == 8) SMF4_LAUNCH(true, 8, *lf);
-        else SMF4_LAUNCH(true, 4, *lf);
+        SMF4_PICK(true, *lf);
     } else if (softmax_final4_usable(x, probs, part, grad, numOut, numCases)) {
-        if (nwOpt == 8) SMF4_LAUNCH(false, 8, LogregFuse{});
-        else SMF4_LAUNCH(false, 4, LogregFuse{});
+        SMF4_PICK(false, LogregFuse{});
     }
+#undef SMF4_PICK
 #undef SMF4_LAUNCH
     else
         hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
@@ -713,7 +721,7 @@ MCN_API int mcn_softmax_logreg_cost_finish(float* labelLogProbs, float* correctP
     return MCN_LAUNCH_CHECK("logreg finish");
 }
 MCN_API int mcn_softmax_logreg_cost_supported(int numOut, int numCases) {
-    return numOut > 0 && numCases > 0 && numCases % 4 == 0 && divup(numOut, SMF4_ROWS) <= 65535 && divup(numOut, SM_ROWS) <= 65535;
+    return numOut > 0 && numCases > 0 && numCases % 4 == 0 && divup(numOut, 128) <= 65535 && divup(numOut, SM_ROWS) <= 65535;
 }
 MCN_API int mcn_softmax_logreg_cost(const float* x, float* probs, const float* labels, float* gradTarget, float coeff, int numOut,
                                     int numCases, const void* part, size_t partBytes, void* workspace, size_t workspaceBytes,

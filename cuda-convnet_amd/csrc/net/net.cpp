@@ -2173,8 +2173,16 @@ void ConvNet::joinGradWork() {
         chk(mcn_flush_tick(), "flush tick");  // (as in waitSideSubmitted)
         _side.wait(_side.pushed());  // the side thread has issued everything it was given
     }
-    chk(timedEventRecord(_evJoin, _gradStream), "event record");
-    chk(timedStreamWait(_stream, _evJoin), "wait event");
+    static const bool joinTick = getenv("MCN_JOIN_TICK") != nullptr;
+    if (joinTick && _tickFlagSide && !_capturing && !g_noHostWait) {
+        // (experiment) this thread polls a tick of the side stream instead of queueing a wait on its own stream
+        const int tick = ++_tickSeqSide;
+        chk(mcn_stream_tick(_tickFlagSide, tick, _gradStream), "stream tick");
+        awaitTick(tick, _tickFlagSide);
+    } else {
+        chk(timedEventRecord(_evJoin, _gradStream), "event record");
+        chk(timedStreamWait(_stream, _evJoin), "wait event");
+    }
     _gradPending = false;
 }
 
