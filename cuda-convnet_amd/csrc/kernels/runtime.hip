@@ -35,8 +35,15 @@ static thread_local struct {
     hipStream_t stream = nullptr;
 } t_tick;
 __global__ void k_stream_tick(volatile int* flag, int value);
-static void tick_send_now() {
+static std::atomic<long> g_tickSent[4];
+static void tick_send_now(int why = 0) {
     if (!t_tick.flag) return;
+    static const bool dbg = getenv("MCN_TICK_DEBUG") != nullptr;
+    if (dbg) {
+        static bool reg = (atexit([] { fprintf(stderr, "tick kernels: behind a launch %ld, flush %ld, re-arm %ld, stream_tick %ld\n", g_tickSent[0].load(), g_tickSent[1].load(), g_tickSent[2].load(), g_tickSent[3].load()); }), true);
+        (void)reg;
+        g_tickSent[why]++;
+    }
     hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value);
     t_tick.flag = nullptr;
 }
@@ -204,14 +211,14 @@ __global__ void k_stream_tick(volatile int* flag, int value) { *flag = value; }
 // it.  mcn_flush_tick sends an armed tick at once (before the caller blocks on whoever waits for it).
 MCN_API int mcn_arm_tick(int* flag, int value, void* stream) {
     MCN_REQUIRE(flag, "armTick: null pointer");
-    tick_send_now();  // (an older one first: ticks of a stream stay in order)
+    tick_send_now(2);  // (an older one first: ticks of a stream stay in order)
     t_tick.flag = flag;
     t_tick.value = value;
     t_tick.stream = (hipStream_t)stream;
     return MCN_OK;
 }
 MCN_API int mcn_flush_tick(void) {
-    tick_send_now();
+    tick_send_now(1);
     return mcn_check_hip(hipGetLastError(), "flushTick");
 }
 MCN_API int mcn_tick_alloc(int** flag) {
@@ -223,7 +230,7 @@ MCN_API int mcn_tick_alloc(int** flag) {
 MCN_API int mcn_tick_free(int* flag) { return flag ? mcn_check_hip(hipHostFree(flag), "hipHostFree (tick)") : MCN_OK; }
 MCN_API int mcn_stream_tick(int* flag, int value, void* stream) {
     MCN_REQUIRE(flag, "streamTick: null pointer");
-    tick_send_now();  // (an armed one first: ticks stay in order)
+    tick_send_now(3);  // (an armed one first: ticks stay in order)
     hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value);
     return mcn_check_hip(hipGetLastError(), "streamTick");
 }

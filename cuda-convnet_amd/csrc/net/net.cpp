@@ -2194,7 +2194,21 @@ void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
         if (d->dataIdx < 0 || d->dataIdx >= (int)_curData.size()) throw NetError("data layer '" + d->name() + "': no data matrix " + std::to_string(d->dataIdx));
         d->setSlice(_curData[d->dataIdx]);  // every data matrix is in place before anything propagates (a fused softmax reads the labels)
     }
-    for (DataLayer* d : _dataLayers) d->fpropData(_curData[d->dataIdx], pt);
+    // Data layers that feed cost layers only (labels, attribute targets) go first: a cost layer starts when its LAST input
+    // arrives, and in cfg order the labels came after the whole image tower had been walked -- the L2-SN cost, which needs
+    // only fc5's output and is forked to the side stream, was forked behind fc6's product and the softmax instead of behind
+    // fc5 (its cost kernel started ~40 us later than it could and the backward chain waited for it).
+    static const bool labelsFirst = getenv("MCN_NO_LABELS_FIRST") == nullptr;
+    auto costOnly = [](DataLayer* d) {
+        for (Layer* l : d->next())
+            if (l->type().compare(0, 5, "cost.") != 0) return false;
+        return true;
+    };
+    if (labelsFirst)
+        for (DataLayer* d : _dataLayers)
+            if (costOnly(d)) d->fpropData(_curData[d->dataIdx], pt);
+    for (DataLayer* d : _dataLayers)
+        if (!labelsFirst || !costOnly(d)) d->fpropData(_curData[d->dataIdx], pt);
 }
 
 void ConvNet::fpropSlice(long start, long end, PassType pt) {
