@@ -303,7 +303,10 @@ def main():
             ks = [roofline_entry(layers, lab, c, ms, mb, fused_pools) for lab, (c, ms) in prof.items() if c > 0]
             ks.sort(key=lambda e: -e['avg_us'] * e['launches'])
             step_us = sum(e['avg_us'] * e['launches'] for e in ks) / a.profile_steps
-            top = dict(ks[0])
+            # the dominant launch among those a roofline says anything about: the L2-SN cost (pair statistics of 160 x 128
+            # features, in data-parallel mode an all-gather) is latency, SURVEY 8d files it under "latency / launch"
+            big = [e for e in ks if op_work(layers, e['op'], mb, fused_pools)[1] >= 1e6]
+            top = dict((big or ks)[0])
             out['roofline'] = {'bound': top['bound'], 'achieved': top['achieved'], 'peak': top['peak'], 'unit': top['unit'],
                                'frac': top['frac'], 'traffic': None, 'kernel': top['op'], 'avg_us': top['avg_us']}
             # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
