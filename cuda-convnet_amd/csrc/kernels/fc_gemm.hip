@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_fc_nn_lds(const FcParams p) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) s4[t] += v[q][r][t] == -INFINITY ? 0.f : expf(v[q][r][t] - m4[t]);
+            for (int t = 0; t < 4; t++) s4[t] += v[q][r][t] == -INFINITY ? 0.f : __expf(v[q][r][t] - m4[t]);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             s4[t] += __shfl_xor(s4[t], 16);

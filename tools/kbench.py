@@ -113,6 +113,7 @@ def main():
             from kutil import dev_double
             cost = dev_double(2)
             call('mcn_gemm_bias_neuron_softmax_part', W, X, b, Y, O_, N, I, 0, 0.0, 0.0, part, nb, None)
+            report(name + ' fwd + softmax stage 1', (lambda: call('mcn_gemm_bias_neuron_softmax_part', W, X, b, Y, O_, N, I, 0, 0.0, 0.0, part, nb, None)), flops, nbytes)
             report(name + ' softmax+grad+cost', (lambda: call('mcn_softmax_logreg_cost', Y, probs, labels, grad, 1.0, O_, N, part, nb, ws, ws.nbytes, lp, cp, cost, state, sb, 1, None)), 4.0 * N * O_, 4.0 * 3 * N * O_)
             report(name + ' softmax+grad+cost w/o finish', (lambda: call('mcn_softmax_logreg_cost', Y, probs, labels, grad, 1.0, O_, N, part, nb, ws, ws.nbytes, lp, cp, cost, state, sb, 0, None)), 4.0 * N * O_, 4.0 * 3 * N * O_)
             call('mcn_softmax_logreg_cost_finish', lp, cp, cost, state, sb, N, None)
