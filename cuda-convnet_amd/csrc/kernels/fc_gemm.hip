@@ -446,7 +446,8 @@ static TnPlan tn_plan(int M, int N, int K) {
     TnPlan pl;
     pl.mg = (M % 80 == 0 || M <= 80) && M > 64 ? 5 : 4;
     const long tiles = (long)divup(M, 16 * pl.mg) * divup(N, 64);
-    long s = std::max<long>(1, 256 / tiles);
+    static const long target = getenv("MCN_TN_BLOCKS") ? atol(getenv("MCN_TN_BLOCKS")) : 256;
+    long s = std::max<long>(1, target / tiles);
     s = std::min<long>(s, std::max(1, K / 64));
     pl.kChunk = divup(divup(K, (int)s), 16) * 16;
     pl.splits = divup(K, pl.kChunk);
