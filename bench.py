@@ -280,9 +280,14 @@ def main():
 
     prof = {}
     if not a.no_profile:
-        lib.startSteps(a.profile_steps, 0, 1)
-        lib.finishBatch()
-        prof = lib.getProfile()
+        # three passes, per operation the pass with the smallest average: one stalled launch (a clock ramp, another tenant of
+        # the box) in 20 would otherwise name the wrong operation as the dominant one
+        for _ in range(3):
+            lib.startSteps(a.profile_steps, 0, 1)
+            lib.finishBatch()
+            for k, (c, ms) in lib.getProfile().items():
+                if k not in prof or (c > 0 and ms / c < prof[k][1] / max(prof[k][0], 1)):
+                    prof[k] = (c, ms)
     lib.destroyModel()
 
     if rank == 0:
