@@ -57,7 +57,7 @@ def single_gpu(name, steps, world=2):
 
 
 @pytest.mark.parametrize('name,steps,world', [('deepid2', 1, 2), ('deepid2', 3, 2), ('deepid2plus', 1, 2), ('deepid-attr', 2, 2),
-                                              ('cifar10', 2, 2), ('deepid2', 2, 4)])
+                                              ('cifar10', 2, 2), ('deepid2', 2, 4), ('deepid2plus', 1, 4)])
 def test_ranks_on_one_gpu_equal_the_single_gpu_step(name, steps, world, tmp_path):
     ranks = run_ranks(name, steps, tmp_path, world)
     r0, r1 = ranks[0], ranks[-1]
