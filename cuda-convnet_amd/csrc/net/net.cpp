@@ -302,21 +302,25 @@ WeightLayer::WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortr
     if (hW.size() != hInc.size() || hW.size() != epsW.size() || hW.size() != momW.size() || hW.size() != wc.size() ||
         hW.size() != srcL.size() || hW.size() != srcM.size())
         throw NetError("layer '" + _name + "': weight parameter lists differ in length");
-    // Weight sharing (`weightSource`, weights.cuh:59-68) is parsed but refused here: no BASELINE config uses it (only an archival
-    // siamese cfg under layers/), there is no parity evidence for it, and the reference's own accumulate rule for a shared FC /
-    // local matrix overwrites all but the last contribution (layer.cu:378, :554).  The sharing constructor below stays for the
-    // day it is covered; until then a net that asks for it fails loudly instead of training on unverified gradients.
-    for (size_t i = 0; i < hW.size(); i++)
-        if (srcL[i] >= 0 && getenv("MCN_ALLOW_WEIGHT_SHARING") == nullptr)
-            throw NetError("layer '" + _name + "': weight sharing (weightSource) is not supported by this build (no parity coverage; "
-                           "see DESIGN.md section 8)");
+    // Weight sharing (`weightSource`, weights.cuh:59-68, layer.cu:277-289): a sharer uses the owner's device matrices with its own
+    // epsW; the update counter lives in the owner.  Every gradient piece of a net that shares weights is issued by ONE
+    // submitting thread on ONE stream (ConvNet::finishSideWork / joinGradWork), in the order of the backward pass, so the
+    // accumulation order -- and for FC / local matrices the reference's own "last contribution wins" rule, layer.cu:378,
+    // :554 -- is the reference's.
     for (size_t i = 0; i < hW.size(); i++) {
         if (srcL[i] == net->numLayers()) {  // current layer (layer.cu:280-281)
-            _weights.emplace_back(new Weights(*_weights.at(srcM[i]), (float)epsW[i]));
+            if (srcM[i] < 0 || srcM[i] >= (long)_weights.size()) throw NetError("layer '" + _name + "': weight source matrix not defined yet");
+            _weights.emplace_back(new Weights(*_weights[srcM[i]], (float)epsW[i]));
+            net->noteWeightSharing();
         } else if (srcL[i] >= 0) {
-            WeightLayer* src = dynamic_cast<WeightLayer*>(&net->layer((int)srcL[i]));
+            WeightLayer* src = srcL[i] < net->numLayers() ? dynamic_cast<WeightLayer*>(&net->layer((int)srcL[i])) : nullptr;
             if (!src) throw NetError("layer '" + _name + "': weight source is not a weight layer");
-            _weights.emplace_back(new Weights(src->weights((int)srcM[i]), (float)epsW[i]));
+            if (srcM[i] < 0 || srcM[i] >= src->numWeights()) throw NetError("layer '" + _name + "': weight source matrix index out of range");
+            Weights& sw = src->weights((int)srcM[i]);
+            if (sw.rows() != hW[i].rows || sw.cols() != hW[i].cols || sw.useGrad() != useGrad)
+                throw NetError("layer '" + _name + "': weight source matrix has another shape or layer type");
+            _weights.emplace_back(new Weights(sw, (float)epsW[i]));
+            net->noteWeightSharing();
         } else {
             _weights.emplace_back(new Weights(hW[i], hInc[i], (float)epsW[i], (float)wc[i], (float)momW[i], useGrad, fortran));
         }
@@ -366,6 +370,15 @@ void WeightLayer::updateWeights() {
 void WeightLayer::weightsUpdated() {
     for (auto& w : _weights) w->updated();
     _biases->updated();
+}
+void WeightLayer::resetUpdateCounters() {
+    for (auto& w : _weights) w->resetUpdates();
+    _biases->resetUpdates();
+}
+bool WeightLayer::sharesWeights() const {
+    for (auto& w : _weights)
+        if (!w->owner()) return true;
+    return false;
 }
 void WeightLayer::copyToCPU() {
     for (auto& w : _weights) w->copyToCPU(_net->stream());
@@ -531,6 +544,7 @@ void FCLayer::bpropWeights(float* v, int i, PassType pt) {
                 is[k] = _prev[k]->outputs();
                 so[k] = gradScale(wk.eps(), pt);
                 st[k] = dp ? (wk.numUpdates() > 0 ? 1.f : 0.f) : ((wk.numUpdates() == 0 && pt != PASS_GC) ? wk.mom() : 0.f);
+                for (int j = 0; j < k; j++) all = all && ts[j] != ts[k];  // (two inputs sharing one matrix: one after the other)
             }
             if (all && mcn_fc_bprop_weights_multi_supported(v, xs.data(), ts.data(), is.data(), cnt, _outputs, n) == 1) {
                 chk(mcn_fc_bprop_weights_multi(v, xs.data(), ts.data(), is.data(), so.data(), st.data(), cnt, _outputs, n, _net->stream()),
@@ -1666,7 +1680,7 @@ void ConvNet::resetAfterError() {
         std::lock_guard<std::mutex> lk(_commMutex);
         _commPending = false;
         _sentUpTo = 0;
-        for (Segment& sg : _segments) sg.ready = sg.byMain = false;
+        for (Segment& sg : _segments) { sg.ready = sg.byMain = false; sg.reported = 0; }
     }
     if (_capturing) {  // a capture must be ended before the stream can be used again
         void* dead = nullptr;
@@ -1680,9 +1694,14 @@ void ConvNet::resetAfterError() {
     for (auto& l : _layers) {
         l->reset();
         l->resetPassFlags();
-        l->weightsUpdated();  // numUpdates = 0: the next pass starts its gradients afresh (what the failed pass added to a
+        l->resetUpdateCounters();  // numUpdates = 0: the next pass starts its gradients afresh (what the failed pass added to a
                               // momentum matrix stays there: the caller decides whether to reload a checkpoint)
     }
+    // the failed pass's softmax has added its per-column tie counts and the launch that clears them (queued in _late) is
+    // gone: without this the next step's correctProbs would be 1 / (2 * ties)
+    for (auto& l : _layers)
+        if (auto* sm = dynamic_cast<SoftmaxLayer*>(l.get()))
+            if (sm->costState.p) mcn_memset(sm->costState.p, 0, sm->costStateBytes, _stream);
     if (_dpOn) _failed = true;
     mcn_device_sync();  // (a sticky device error shows up in the next call's status)
 }
@@ -1744,6 +1763,21 @@ void ConvNet::allocate(int maxCases) {
         }
         if (total > begin) _segments.push_back({wl, begin, total, false});
     }
+    // a segment is complete when its layer AND every layer sharing one of its matrices have written their gradients
+    for (Segment& sg : _segments) {
+        sg.contributors.assign(1, sg.layer);
+        for (auto& l : _layers) {
+            auto* other = dynamic_cast<WeightLayer*>(l.get());
+            if (!other || other == sg.layer) continue;
+            bool shares = false;
+            for (int k = 0; k < other->numWeights() && !shares; k++) {
+                Weights& w = other->weights(k);
+                if (w.owner()) continue;
+                for (int j = 0; j < sg.layer->numWeights(); j++) shares = shares || w.W() == sg.layer->weights(j).W();
+            }
+            if (shares) sg.contributors.push_back(other);
+        }
+    }
     _gradArena.ensure(std::max<size_t>(total, 4));
     chk(mcn_memset(_gradArena.p, 0, _gradArena.cap * 4, _stream), "memset grads");
     for (auto& pw : place) pw.first->setGradBuf(_gradArena.p + pw.second);
@@ -1784,6 +1818,16 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     _rank = rank;
     _world = world;
     _dpOn = world > 1 || force;
+    if (_dpOn && _hasSharing)
+        for (auto& l : _layers)
+            if (auto* wl = dynamic_cast<WeightLayer*>(l.get()))
+                for (int k = 0; k < wl->numWeights(); k++)
+                    if (!wl->weights(k).owner() && !wl->weights(k).useGrad()) {
+                        // layer.cu:378, :554: a second contribution to a shared FC / local matrix REPLACES the increment, momentum
+                        // included; replicas exchange raw gradients and fold the momentum in afterwards, which cannot restate that
+                        _dpOn = false;
+                        throw NetError("layer '" + wl->name() + "': shared fc / local weights are not defined for data-parallel replicas");
+                    }
     dropStepGraphs();
     if (_dpOn) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
@@ -2127,7 +2171,9 @@ void ConvNet::joinExchange() {
 void ConvNet::finishSideWork() {
     // what is still deferred has no backward-data work left to hide behind: half goes to the side stream, the
     // rest runs on the main stream next to it
-    if (_deferredUnits >= 2) {
+    if (_hasSharing && _gradStream && !_profiling) {
+        flushSideWork(_deferred.size());  // shared matrices: every contribution on the side stream, in pass order
+    } else if (_deferredUnits >= 2) {
         size_t cut = 0;
         for (int units = 0; cut < _deferred.size() && units < _deferredUnits / 2; cut++) units += _deferred[cut].second;
         flushSideWork(cut);
@@ -2160,6 +2206,7 @@ void ConvNet::runLateWork() {
 }
 
 void ConvNet::joinGradWork() {
+    if (_hasSharing && _gradStream && !_profiling && !_deferred.empty()) flushSideWork(_deferred.size());  // (never a sharer's piece on the main stream)
     if (!_deferred.empty()) {
         auto rest = std::move(_deferred);
         _deferred.clear();
@@ -2330,13 +2377,14 @@ void ConvNet::gradReady(WeightLayer* l) {
     {
         std::lock_guard<std::mutex> lk(_commMutex);
         for (Segment& s : _segments)
-            if (s.layer == l) {
-                s.ready = true;
+            if (std::find(s.contributors.begin(), s.contributors.end(), l) != s.contributors.end()) {
                 // which stream(s) hold the kernels that wrote it: the side thread issues both of a layer's pieces on the
                 // side stream; on the main thread the bias piece may have gone to the side stream (last layer of a pass)
-                s.onSide = t_stream == 1 || _gradPending;
-                s.onMain = t_stream != 1;
-                s.byMain = t_stream != 1;
+                const bool first = s.reported == 0;
+                s.onSide = (first ? false : s.onSide) || t_stream == 1 || _gradPending;
+                s.onMain = (first ? false : s.onMain) || t_stream != 1;
+                s.byMain = (first ? false : s.byMain) || t_stream != 1;
+                s.ready = ++s.reported >= (int)s.contributors.size();
             }
     }
     // Only the side thread decides where a bucket ends: it sees the layers in one fixed order on every rank.  A layer
@@ -2416,7 +2464,7 @@ void ConvNet::waitComm() {
         _commPending = false;
     }
     _sentUpTo = 0;
-    for (Segment& s : _segments) s.ready = s.byMain = false;
+    for (Segment& s : _segments) { s.ready = s.byMain = false; s.reported = 0; }
 }
 
 void ConvNet::allGather2(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
@@ -2542,7 +2590,7 @@ void ConvNet::checkGradients(std::vector<GradCheckResult>& out, long maxElems, b
     auto restore = [&] {
         joinGradWork();
         for (auto& sv : saved) chk(mcn_d2d(sv.first->inc(), sv.second->p, sv.first->size() * 4, _stream), "d2d inc");
-        for (auto& l : _layers) l->weightsUpdated();  // (numUpdates back to 0: the next training pass starts a fresh gradient)
+        for (auto& l : _layers) l->resetUpdateCounters();  // (numUpdates back to 0: the next training pass starts a fresh gradient)
         sync();
     };
     try {

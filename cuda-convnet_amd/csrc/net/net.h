@@ -81,7 +81,8 @@ class Weights {
     void copyToCPU(void* stream);
     void update(bool dp, void* stream);  // weights.cuh:150-163, one fused kernel
     bool planItem(bool dp, ::mcn_sgd_item& it);  // record for the all-matrices update; false: nothing to update
-    void updated() { if (!_src) _numUpdates = 0; }
+    void updated() { if (!_src && _eps > 0) _numUpdates = 0; }  // weights.cuh:152,161: only an owner that updates resets the counter
+    void resetUpdates() { if (!_src) _numUpdates = 0; }         // (after a failed pass / a gradient check)
     // host <-> device image conversion for gradient checking
     void hostImage(std::vector<float>& out, void* stream);        // logical (rows, cols) row-major
     void setElement(long r, long c, float v, void* stream);
@@ -127,6 +128,7 @@ class Layer {
     virtual size_t workspaceBytes(int maxCases) { return 0; }
     virtual void updateWeights() {}
     virtual void weightsUpdated() {}
+    virtual void resetUpdateCounters() {}
     virtual void copyToCPU() {}
     virtual void copyToGPU() {}
     virtual void checkGradients(std::vector<struct GradCheckResult>& out, long maxElems, bool central) {}
@@ -187,6 +189,8 @@ class WeightLayer : public Layer {
     WeightLayer(ConvNet* net, const Params& p, bool useGrad, bool fortran);
     void updateWeights() override;
     void weightsUpdated() override;
+    void resetUpdateCounters() override;
+    bool sharesWeights() const;  // holds a matrix that another Weights object owns
     void copyToCPU() override;
     void copyToGPU() override;
     void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) override;
@@ -747,6 +751,9 @@ class ConvNet {
     struct SegmentInfo { std::string layer; size_t begin, end; };
     std::vector<SegmentInfo> gradSegments();
     size_t bucketFloats() const { return _bucketFloats; }
+    // weightSource nets: every gradient piece on the side stream, in pass order (see WeightLayer::WeightLayer)
+    void noteWeightSharing() { _hasSharing = true; }
+    bool hasWeightSharing() const { return _hasSharing; }
     void setFusion(bool on) { _fusion = on; }
     bool fusion() const { return _fusion; }
     bool profiling() const { return _profiling; }
@@ -768,6 +775,7 @@ class ConvNet {
     int _numCases = 0;
     int _allocatedCases = 0;
     bool _fusion = true;
+    bool _hasSharing = false;
     std::vector<float*> _curData;
 
     void* _stream = nullptr;
@@ -823,7 +831,11 @@ class ConvNet {
     int _sideUnits = 2, _wlSeen = 0, _wlPerPass = 0;
     void* _evGather = nullptr;
     void* _evComm = nullptr;
-    struct Segment { WeightLayer* layer; size_t begin, end; bool ready; bool onSide = false, onMain = true, byMain = false; };
+    struct Segment {
+        WeightLayer* layer; size_t begin, end; bool ready; bool onSide = false, onMain = true, byMain = false;
+        std::vector<WeightLayer*> contributors;  // the layer itself and every layer that shares one of its matrices
+        int reported = 0;                        // ... of which so many have finished their gradients in this pass
+    };
     std::vector<Segment> _segments;  // in arena order (reverse layer order)
     size_t _sentUpTo = 0;            // arena offset up to which all-reduce has been issued
     size_t _bucketFloats = 1 << 20;

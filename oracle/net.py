@@ -23,17 +23,47 @@ PASS_TRAIN, PASS_TEST, PASS_GC = 0, 1, 2
 
 
 class Weights:
-    """weights.cuh:41-198 (no weight sharing: 'next' scope)."""
+    """weights.cuh:41-198, including shared matrices (`Weights(Weights& srcWeights, float epsW)`, :59-68): a sharer
+    has its own epsW, weight decay 0, and the owner's momentum / useGrad / device matrices (copyToGPU :141-145);
+    the update counter lives in the owner (:165-181) and only the owner updates (:150-163)."""
 
-    def __init__(self, w, inc, eps, wc, mom, use_grad, fortran):
+    def __init__(self, w, inc, eps, wc, mom, use_grad, fortran, src=None):
         # host arrays keep the caller's layout; `W`/`inc` below are the flat memory images
+        self.src = src.src if (src is not None and src.src is not None) else src
         self.hW, self.hInc = w, inc
         self.fortran = fortran
-        self.W = self._mem(w).copy()
-        self.inc = self._mem(inc).copy()
-        self.grad = np.zeros_like(self.W) if use_grad else None
-        self.eps, self.wc, self.mom, self.use_grad = eps, wc, mom, use_grad
-        self.num_updates = 0
+        if self.src is not None:
+            o = self.src
+            self.W, self.inc, self._grad = o.W, o.inc, None
+            self.eps, self.wc, self.mom, self.use_grad = eps, 0.0, o.mom, o.use_grad
+        else:
+            self.W = self._mem(w).copy()
+            self.inc = self._mem(inc).copy()
+            self._grad = np.zeros_like(self.W) if use_grad else None
+            self.eps, self.wc, self.mom, self.use_grad = eps, wc, mom, use_grad
+        self._num_updates = 0
+
+    @property
+    def grad(self):
+        return self.src._grad if self.src is not None else self._grad
+
+    @grad.setter
+    def grad(self, g):
+        if self.src is not None:
+            self.src._grad = g
+        else:
+            self._grad = g
+
+    @property
+    def num_updates(self):  # weights.cuh:176-181
+        return self.src._num_updates if self.src is not None else self._num_updates
+
+    @num_updates.setter
+    def num_updates(self, v):  # weights.cuh:165-170
+        if self.src is not None:
+            self.src._num_updates = v
+        else:
+            self._num_updates = v
 
     def _mem(self, a):
         return np.ascontiguousarray(a.T) if self.fortran else np.ascontiguousarray(a)
@@ -44,13 +74,15 @@ class Weights:
         return self.grad if (self.use_grad or dp) else self.inc
 
     def update(self, comm=None):
-        if self.eps > 0:
+        if self.src is None and self.eps > 0:  # "Only true owner of weights updates" (weights.cuh:152)
             if comm is not None:  # data-parallel: raw scaled gradients are summed over the replicas first
                 comm.all_reduce(self.get_grad(True))
             K.sgd_update(self.W, self.inc, self.grad, self.mom, self.wc, self.eps, self.use_grad or comm is not None)
             self.num_updates = 0
 
     def copy_to_host(self):
+        if self.src is not None:  # weights.cuh:124-130
+            return
         self.hW[...] = self.W.T if self.fortran else self.W
         self.hInc[...] = self.inc.T if self.fortran else self.inc
 
@@ -183,9 +215,15 @@ class NeuronLayer(Layer):
 class WeightLayer(Layer):
     def __init__(self, net, d, use_grad, fortran):
         super().__init__(net, d)
-        assert all(i < 0 for i in d['weightSourceLayerIndices']), 'weight sharing is outside the oracle scope'
-        self.weights = [Weights(w, wi, e, c, m, use_grad, fortran)
-                        for w, wi, e, c, m in zip(d['weights'], d['weightsInc'], d['epsW'], d['wc'], d['momW'])]
+        self.weights = []
+        for i, (w, wi, e, c, m) in enumerate(zip(d['weights'], d['weightsInc'], d['epsW'], d['wc'], d['momW'])):
+            li, mi = d['weightSourceLayerIndices'][i], d['weightSourceMatrixIndices'][i]
+            src = None
+            if li == len(net.layers):  # the layer being built (layer.cu:280-281)
+                src = self.weights[mi]
+            elif li >= 0:  # layer.cu:282-285
+                src = net.layers[li].weights[mi]
+            self.weights.append(Weights(w, wi, e, c, m, use_grad, fortran, src=src))
         self.biases = Weights(d['biases'], d['biasesInc'], d['epsB'], 0.0, d['momB'], True, False)
         # biases are vectors: their memory image is layout independent
         self.biases.W = np.ascontiguousarray(d['biases']).reshape(-1).copy()

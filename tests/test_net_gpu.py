@@ -477,8 +477,9 @@ def test_a_failed_step_leaves_a_usable_model(name, layer):
     dp, L = preset(name, 256)
     data = dp.get_next_batch()[2]
     with Native(L) as lib:
-        lib.startBatch(data, 0)
-        lib.finishBatch()
+        for _ in range(6 if name == 'cifar10' else 1):  # (cifar10: until some cases are classified correctly, see below)
+            lib.startBatch(data, 0)
+            lib.finishBatch()
         lib.failNextBackwardAt(layer)
         lib.startBatch(data, 0)
         with pytest.raises(RuntimeError, match='injected failure'):
@@ -498,6 +499,13 @@ def test_a_failed_step_leaves_a_usable_model(name, layer):
         lib.syncWithHost()
     assert cost_a == cost_b and test_a == test_b
     assert all(np.isfinite(v).all() for v in cost_a[0].values())
+    # the failed pass's forward left per-column tie counts behind (its finishing launch never ran): a step after the
+    # recovery must still count whole errors, and on cifar10 some cases must be hits for that to mean anything
+    errs = cost_a[0]['logprob'][1]
+    assert errs == int(errs), cost_a
+    if name == 'cifar10':
+        assert errs < 256, 'no correctly classified case: the tie counters are not exercised'
+
     for la, lb in zip(L, L2):
         if 'weights' not in la:
             continue
