@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <time.h>
 #include "../../../include/mi_convnet.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -22,6 +23,20 @@ int mcn_check_hip(hipError_t e, const char* what);
     } while (0)
 
 int mcn_launch_check(const char* what);  // hipGetLastError + this thread's launch counter (mcn_launch_count)
+// every kernel launch of the library: the host time inside the runtime's launch call is accumulated per calling thread
+// (mcn_launch_ns) so that a caller can tell submission cost from time it spent blocked (bench.py host_breakdown)
+extern thread_local uint64_t t_mcnLaunchNs;
+static inline uint64_t mcn_now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+#define MCN_LAUNCH(...)                              \
+    do {                                             \
+        const uint64_t mcnT0_ = mcn_now_ns();        \
+        hipLaunchKernelGGL(__VA_ARGS__);             \
+        t_mcnLaunchNs += mcn_now_ns() - mcnT0_;      \
+    } while (0)
 #define MCN_LAUNCH_CHECK(name) mcn_launch_check(name)
 
 // A tick armed by mcn_arm_tick for this thread's next launch on `stream`: a kernel that supports it takes (flag, value) into

@@ -251,31 +251,31 @@ static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipeli
     if (p.uTarget) {  // (vecn: checked by the caller)
 #define MCN_UNDO_LAUNCH(UN)                                                                                               \
     do {                                                                                                                  \
-        if (pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U, 1, UN>), grid, dim3(256), 0, s, p);                \
+        if (pipelined) MCN_LAUNCH((k_img_acts<CV, NQ, true, U, 1, UN>), grid, dim3(256), 0, s, p);                \
         else if (ksplit) {                                                                                                \
             if constexpr (CV == 1 && NQ == 1) {                                                                           \
                 grid.y = divup(p.imgY * p.imgX, 4 / ksplit);                                                              \
-                if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
-                else hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
+                if (ksplit == 4) MCN_LAUNCH((k_img_acts<1, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
+                else MCN_LAUNCH((k_img_acts<1, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
             } else if constexpr (CV == 2 && NQ == 1) {                                                                    \
                 grid.y = divup(p.imgY * p.imgX, 4 / ksplit);                                                              \
-                if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
-                else hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
+                if (ksplit == 4) MCN_LAUNCH((k_img_acts<2, 1, true, 2, 4, UN>), grid, dim3(256), 0, s, p);        \
+                else MCN_LAUNCH((k_img_acts<2, 1, true, 2, 2, UN>), grid, dim3(256), 0, s, p);                    \
             }                                                                                                             \
-        } else hipLaunchKernelGGL((k_img_acts<CV, NQ, true, 1, 1, UN>), grid, dim3(256), 0, s, p);                        \
+        } else MCN_LAUNCH((k_img_acts<CV, NQ, true, 1, 1, UN>), grid, dim3(256), 0, s, p);                        \
     } while (0)
         if (p.uNeuron == MCN_NEURON_RELU) MCN_UNDO_LAUNCH(2);
         else MCN_UNDO_LAUNCH(1);
 #undef MCN_UNDO_LAUNCH
         return;
     }
-    if (vecn && pipelined) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, U>), grid, dim3(256), 0, s, p);
+    if (vecn && pipelined) MCN_LAUNCH((k_img_acts<CV, NQ, true, U>), grid, dim3(256), 0, s, p);
     else if (vecn && ksplit) {
         if constexpr (CV == 2 && NQ == 1) {
             grid.y = divup(p.imgY * p.imgX, 4 / ksplit);
             // (two 16-channel tiles per wave halve the re-reads of the gradient rows; 4 steps per register set: conv2+ 92 -> 85 us)
-            if (ksplit == 4) hipLaunchKernelGGL((k_img_acts<2, 1, true, 4, 4>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_img_acts<2, 1, true, 2, 2>), grid, dim3(256), 0, s, p);
+            if (ksplit == 4) MCN_LAUNCH((k_img_acts<2, 1, true, 4, 4>), grid, dim3(256), 0, s, p);
+            else MCN_LAUNCH((k_img_acts<2, 1, true, 2, 2>), grid, dim3(256), 0, s, p);
         }
         if constexpr (CV == 1 && NQ == 1) {
             grid.y = divup(p.imgY * p.imgX, 4 / ksplit);  // 4 / KS pixels per block
@@ -283,18 +283,18 @@ static void launch_bd2(const BwdDataParams& p, dim3 grid, bool vecn, bool pipeli
             // 14.2 -> 12.7 us alone; 4 gains nothing more).  MCN_IA_U overrides (A/B).
             static const int uexp = getenv("MCN_IA_U") ? atoi(getenv("MCN_IA_U")) : 2;
             if (ksplit == 4) {
-                if (uexp == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 4, 4>), grid, dim3(256), 0, s, p);
-                else if (uexp == 2) hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 4>), grid, dim3(256), 0, s, p);
-                else hipLaunchKernelGGL((k_img_acts<1, 1, true, 1, 4>), grid, dim3(256), 0, s, p);
+                if (uexp == 4) MCN_LAUNCH((k_img_acts<1, 1, true, 4, 4>), grid, dim3(256), 0, s, p);
+                else if (uexp == 2) MCN_LAUNCH((k_img_acts<1, 1, true, 2, 4>), grid, dim3(256), 0, s, p);
+                else MCN_LAUNCH((k_img_acts<1, 1, true, 1, 4>), grid, dim3(256), 0, s, p);
             } else {
-                if (uexp == 4) hipLaunchKernelGGL((k_img_acts<1, 1, true, 4, 2>), grid, dim3(256), 0, s, p);
-                else if (uexp == 2) hipLaunchKernelGGL((k_img_acts<1, 1, true, 2, 2>), grid, dim3(256), 0, s, p);
-                else hipLaunchKernelGGL((k_img_acts<1, 1, true, 1, 2>), grid, dim3(256), 0, s, p);
+                if (uexp == 4) MCN_LAUNCH((k_img_acts<1, 1, true, 4, 2>), grid, dim3(256), 0, s, p);
+                else if (uexp == 2) MCN_LAUNCH((k_img_acts<1, 1, true, 2, 2>), grid, dim3(256), 0, s, p);
+                else MCN_LAUNCH((k_img_acts<1, 1, true, 1, 2>), grid, dim3(256), 0, s, p);
             }
         }
     }
-    else if (vecn) hipLaunchKernelGGL((k_img_acts<CV, NQ, true, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_img_acts<CV, NQ, false, 1>), grid, dim3(256), 0, s, p);
+    else if (vecn) MCN_LAUNCH((k_img_acts<CV, NQ, true, 1>), grid, dim3(256), 0, s, p);
+    else MCN_LAUNCH((k_img_acts<CV, NQ, false, 1>), grid, dim3(256), 0, s, p);
 }
 
 template <int CV>

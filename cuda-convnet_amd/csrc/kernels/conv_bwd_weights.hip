@@ -232,9 +232,9 @@ template <int KV, int FV>
 static void launch_bw2(const BwdWParams& p, dim3 grid, size_t lds, bool vecn, hipStream_t s) {
     const size_t imgBytes = (size_t)p.C * p.imgY * p.imgX * p.imgStride * 4, hidBytes = (size_t)p.F * p.mY * p.mX * p.N * 4;
     const bool buf = vecn && imgBytes < (1u << 31) && hidBytes < (1u << 31);
-    if (buf) hipLaunchKernelGGL((k_weight_acts<KV, FV, 2>), grid, dim3(256), lds, s, p);
-    else if (vecn) hipLaunchKernelGGL((k_weight_acts<KV, FV, 1>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_weight_acts<KV, FV, 0>), grid, dim3(256), lds, s, p);
+    if (buf) MCN_LAUNCH((k_weight_acts<KV, FV, 2>), grid, dim3(256), lds, s, p);
+    else if (vecn) MCN_LAUNCH((k_weight_acts<KV, FV, 1>), grid, dim3(256), lds, s, p);
+    else MCN_LAUNCH((k_weight_acts<KV, FV, 0>), grid, dim3(256), lds, s, p);
 }
 
 static int weight_acts_check(const float* images, const float* hidActs, float* targets, int N, int imgStride,
@@ -501,8 +501,8 @@ static StripPlan strip_plan(int C, int F, int fs, int mY, int mX, int stride, in
 
 template <int KT>
 static void launch_strip(const StripParams& p, const StripPlan& pl, dim3 grid, hipStream_t s) {
-    if (pl.FV == 2) hipLaunchKernelGGL((k_conv_wgrad_strip<KT, 2>), grid, dim3(256), pl.lds, s, p);
-    else hipLaunchKernelGGL((k_conv_wgrad_strip<KT, 1>), grid, dim3(256), pl.lds, s, p);
+    if (pl.FV == 2) MCN_LAUNCH((k_conv_wgrad_strip<KT, 2>), grid, dim3(256), pl.lds, s, p);
+    else MCN_LAUNCH((k_conv_wgrad_strip<KT, 1>), grid, dim3(256), pl.lds, s, p);
 }
 
 // module split of the fused reduction: enough chunks to fill the chip, few enough to keep the
@@ -563,7 +563,7 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
         }
         rc = MCN_LAUNCH_CHECK("convWeightActsReduced");
         if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, s, (const float*)workspace, grad, pl.strips, cols, scaleTargets);
+        MCN_LAUNCH(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, s, (const float*)workspace, grad, pl.strips, cols, scaleTargets);
         return MCN_LAUNCH_CHECK("convWeightActsReduced");
     }
     const int mpc = reduced_modules_per_chunk(M, K, numFilters);
@@ -577,7 +577,7 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
                             numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
                             mpc, 0.f, scaleOutput, (hipStream_t)stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
+    MCN_LAUNCH(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, grad, chunks, cols, scaleTargets);
     return MCN_LAUNCH_CHECK("convWeightActsReduced");
 }

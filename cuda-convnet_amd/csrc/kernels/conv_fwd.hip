@@ -370,11 +370,11 @@ template <int FV, int UB>
 static void launch_fast2(const FwdParams& p, dim3 grid, size_t lds, hipStream_t s) {
     const bool relu = p.neuron == MCN_NEURON_RELU;
     if (p.check) {
-        if (relu) hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, true, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, true, false>), grid, dim3(256), lds, s, p);
+        if (relu) MCN_LAUNCH((k_conv_fwd_fast<FV, UB, true, true>), grid, dim3(256), lds, s, p);
+        else MCN_LAUNCH((k_conv_fwd_fast<FV, UB, true, false>), grid, dim3(256), lds, s, p);
     } else {
-        if (relu) hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, false, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((k_conv_fwd_fast<FV, UB, false, false>), grid, dim3(256), lds, s, p);
+        if (relu) MCN_LAUNCH((k_conv_fwd_fast<FV, UB, false, true>), grid, dim3(256), lds, s, p);
+        else MCN_LAUNCH((k_conv_fwd_fast<FV, UB, false, false>), grid, dim3(256), lds, s, p);
     }
 }
 
@@ -383,19 +383,19 @@ static void launch_fwd3(const FwdParams& p, dim3 grid, size_t lds, bool vecn, bo
     if (ksplit && vecn && p.mw >= 8) {  // (mw doubles as wave count + batch size of the split form: 8 + U)
         if constexpr (NQ == 1 && U <= 8 && FV <= 3) {
             const int u8 = p.mw - 8;
-            if (u8 == 9) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 9, true, true, 8>), grid, dim3(512), lds, s, p);
-            else if (u8 == 6) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 6, true, true, 8>), grid, dim3(512), lds, s, p);
-            else if (u8 == 8) hipLaunchKernelGGL((k_filter_acts<FV, NQ, 8, true, true, 8>), grid, dim3(512), lds, s, p);
-            else hipLaunchKernelGGL((k_filter_acts<FV, NQ, 4, true, true, 8>), grid, dim3(512), lds, s, p);
+            if (u8 == 9) MCN_LAUNCH((k_filter_acts<FV, NQ, 9, true, true, 8>), grid, dim3(512), lds, s, p);
+            else if (u8 == 6) MCN_LAUNCH((k_filter_acts<FV, NQ, 6, true, true, 8>), grid, dim3(512), lds, s, p);
+            else if (u8 == 8) MCN_LAUNCH((k_filter_acts<FV, NQ, 8, true, true, 8>), grid, dim3(512), lds, s, p);
+            else MCN_LAUNCH((k_filter_acts<FV, NQ, 4, true, true, 8>), grid, dim3(512), lds, s, p);
             return;
         }
     }
     if (ksplit) {
-        if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, true, false>), grid, dim3(256), lds, s, p);
+        if (vecn) MCN_LAUNCH((k_filter_acts<FV, NQ, U, true, true>), grid, dim3(256), lds, s, p);
+        else MCN_LAUNCH((k_filter_acts<FV, NQ, U, true, false>), grid, dim3(256), lds, s, p);
     } else {
-        if (vecn) hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, false, true>), grid, dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((k_filter_acts<FV, NQ, U, false, false>), grid, dim3(256), lds, s, p);
+        if (vecn) MCN_LAUNCH((k_filter_acts<FV, NQ, U, false, true>), grid, dim3(256), lds, s, p);
+        else MCN_LAUNCH((k_filter_acts<FV, NQ, U, false, false>), grid, dim3(256), lds, s, p);
     }
 }
 

@@ -59,9 +59,9 @@ MCN_API int mcn_neuron_fwd(const float* in, float* out, size_t n, int neuron, fl
         return MCN_OK;
     }
     if (neuron == MCN_NEURON_RELU && n % 4 == 0 && al16(in) && al16(out))
-        hipLaunchKernelGGL(k_relu_fwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)in, (f32x4*)out, n / 4);
+        MCN_LAUNCH(k_relu_fwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)in, (f32x4*)out, n / 4);
     else
-        hipLaunchKernelGGL(k_neuron_fwd, dim3(ew_blocks(n)), dim3(256), 0, s, in, out, n, neuron, a, b);
+        MCN_LAUNCH(k_neuron_fwd, dim3(ew_blocks(n)), dim3(256), 0, s, in, out, n, neuron, a, b);
     return MCN_LAUNCH_CHECK("neuronFwd");
 }
 
@@ -76,10 +76,10 @@ MCN_API int mcn_neuron_bwd(const float* actsGrad, const float* acts, const float
     hipStream_t s = (hipStream_t)stream;
     if (neuron == MCN_NEURON_IDENT && !add && target == actsGrad) return MCN_OK;
     if (neuron == MCN_NEURON_RELU && n % 4 == 0 && al16(actsGrad) && al16(acts) && al16(target))
-        hipLaunchKernelGGL(k_relu_bwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)actsGrad, (const f32x4*)acts,
+        MCN_LAUNCH(k_relu_bwd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (const f32x4*)actsGrad, (const f32x4*)acts,
                            (f32x4*)target, n / 4, add);
     else
-        hipLaunchKernelGGL(k_neuron_bwd, dim3(ew_blocks(n)), dim3(256), 0, s, actsGrad, acts, inputs, target, n, neuron, a, b, add);
+        MCN_LAUNCH(k_neuron_bwd, dim3(ew_blocks(n)), dim3(256), 0, s, actsGrad, acts, inputs, target, n, neuron, a, b, add);
     return MCN_LAUNCH_CHECK("neuronBwd");
 }
 
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_add_vector(float* mat, const float* vec
 }
 MCN_API int mcn_add_vector(float* mat, const float* vec, int rows, int cols, int perRow, float scale, void* stream) {
     MCN_REQUIRE(mat && vec && rows > 0 && cols > 0, "addVector: bad argument");
-    hipLaunchKernelGGL(k_add_vector, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, mat, vec, rows, cols, perRow, scale);
+    MCN_LAUNCH(k_add_vector, dim3(ew_blocks((size_t)rows * cols)), dim3(256), 0, (hipStream_t)stream, mat, vec, rows, cols, perRow, scale);
     return MCN_LAUNCH_CHECK("addVector");
 }
 
@@ -210,11 +210,11 @@ MCN_API int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int ax
     MCN_REQUIRE(tgt && mat && rows > 0 && cols > 0 && (axis == 0 || axis == 1), "addSum: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (axis == 0) {
-        hipLaunchKernelGGL(k_col_sum, dim3(divup(cols, 256)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
+        MCN_LAUNCH(k_col_sum, dim3(divup(cols, 256)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
     } else if (cols <= 256) {
-        hipLaunchKernelGGL(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
+        MCN_LAUNCH(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, mat, tgt, rows, cols, scaleThis, scaleSum);
     } else if (cols <= ROWSUM_CHUNK) {
-        hipLaunchKernelGGL(k_row_sum, dim3(rows, 1), dim3(256), 0, s, mat, tgt, cols, 1, 1, scaleThis, scaleSum);
+        MCN_LAUNCH(k_row_sum, dim3(rows, 1), dim3(256), 0, s, mat, tgt, cols, 1, 1, scaleThis, scaleSum);
     } else {
         const int chunks = divup(cols, ROWSUM_CHUNK);
         const size_t need = (size_t)rows * chunks * sizeof(float);
@@ -223,11 +223,11 @@ MCN_API int mcn_add_sum(float* tgt, const float* mat, int rows, int cols, int ax
             return MCN_EWORKSPACE;
         }
         MCN_REQUIRE(chunks <= 65535, "addSum: row too long");
-        hipLaunchKernelGGL(k_row_sum, dim3(rows, chunks), dim3(256), 0, s, mat, (float*)workspace, cols, chunks, 0, 0.f, 1.f);
+        MCN_LAUNCH(k_row_sum, dim3(rows, chunks), dim3(256), 0, s, mat, (float*)workspace, cols, chunks, 0, 0.f, 1.f);
         if (chunks <= 256)
-            hipLaunchKernelGGL(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, (const float*)workspace, tgt, rows, chunks, scaleThis, scaleSum);
+            MCN_LAUNCH(k_row_sum_short, dim3(divup(rows, 4)), dim3(256), 0, s, (const float*)workspace, tgt, rows, chunks, scaleThis, scaleSum);
         else
-            hipLaunchKernelGGL(k_row_sum, dim3(rows, 1), dim3(256), 0, s, (const float*)workspace, tgt, chunks, 1, 1, scaleThis, scaleSum);
+            MCN_LAUNCH(k_row_sum, dim3(rows, 1), dim3(256), 0, s, (const float*)workspace, tgt, chunks, 1, 1, scaleThis, scaleSum);
     }
     return MCN_LAUNCH_CHECK("addSum");
 }
@@ -273,8 +273,8 @@ MCN_API int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* wo
         }
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_row_sums_multi, dim3(blocks1), dim3(256), 0, s, s1);
-    if (s2.count > 0) hipLaunchKernelGGL(k_row_sums_multi, dim3(blocks2), dim3(256), 0, s, s2);
+    MCN_LAUNCH(k_row_sums_multi, dim3(blocks1), dim3(256), 0, s, s1);
+    if (s2.count > 0) MCN_LAUNCH(k_row_sums_multi, dim3(blocks2), dim3(256), 0, s, s2);
     return MCN_LAUNCH_CHECK("addSumMulti");
 }
 
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_axpby(float* a, const float* b, size_t 
 MCN_API int mcn_axpby(float* a, const float* b, size_t n, float sa, float sb, void* stream) {
     MCN_REQUIRE(a && b, "axpby: null pointer");
     if (n == 0) return MCN_OK;
-    hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, sa, sb);
+    MCN_LAUNCH(k_axpby, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, sa, sb);
     return MCN_LAUNCH_CHECK("axpby");
 }
 __global__ __launch_bounds__(256) void k_scale(const float* in, float* out, size_t n, float sc) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_scale(const float* in, float* out, size
 MCN_API int mcn_scale(const float* in, float* out, size_t n, float sc, void* stream) {
     MCN_REQUIRE(in && out, "scale: null pointer");
     if (n == 0) return MCN_OK;
-    hipLaunchKernelGGL(k_scale, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, sc);
+    MCN_LAUNCH(k_scale, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, in, out, n, sc);
     return MCN_LAUNCH_CHECK("scale");
 }
 __global__ __launch_bounds__(256) void k_eltmax(const float* a, const float* b, float* out, size_t n) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_eltmax(const float* a, const float* b, 
 MCN_API int mcn_eltwise_max(const float* a, const float* b, float* out, size_t n, void* stream) {
     MCN_REQUIRE(a && b && out, "eltwiseMax: null pointer");
     if (n == 0) return MCN_OK;
-    hipLaunchKernelGGL(k_eltmax, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    MCN_LAUNCH(k_eltmax, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     return MCN_LAUNCH_CHECK("eltwiseMax");
 }
 __global__ __launch_bounds__(256) void k_eltmax_grad(const float* g, const float* in, const float* out, float* tgt, size_t n, int add) {
@@ -315,7 +315,7 @@ MCN_API int mcn_eltwise_max_grad(const float* actGrad, const float* input, const
                                  int add, void* stream) {
     MCN_REQUIRE(actGrad && input && output && target, "eltwiseMaxGrad: null pointer");
     if (n == 0) return MCN_OK;
-    hipLaunchKernelGGL(k_eltmax_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, actGrad, input, output, target, n, add);
+    MCN_LAUNCH(k_eltmax_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, actGrad, input, output, target, n, add);
     return MCN_LAUNCH_CHECK("eltwiseMaxGrad");
 }
 
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_sum_all(const float* a, size_t n, doubl
 }
 MCN_API int mcn_sum_all(const float* a, size_t n, double* outDevice, int accumulate, void* stream) {
     MCN_REQUIRE(a && outDevice, "sumAll: null pointer");
-    hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, (hipStream_t)stream, a, n, outDevice, accumulate);
+    MCN_LAUNCH(k_sum_all, dim3(1), dim3(256), 0, (hipStream_t)stream, a, n, outDevice, accumulate);
     return MCN_LAUNCH_CHECK("sumAll");
 }
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src
 }
 MCN_API int mcn_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
     MCN_REQUIRE(src && dst && rows > 0 && cols > 0 && src != dst, "transpose: bad argument");
-    hipLaunchKernelGGL(k_transpose, dim3(divup(cols, 32), divup(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+    MCN_LAUNCH(k_transpose, dim3(divup(cols, 32), divup(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
     return MCN_LAUNCH_CHECK("transpose");
 }
 
@@ -656,7 +656,7 @@ static int softmax_final_launch(const float* x, float* probs, const float* part,
     const int rows = rowsOpt == 512 ? 512 : rowsOpt == 128 ? 128 : 256, nw = nwOpt == 4 ? 4 : 8;
     const dim3 grid4(divup(numCases, 32), divup(numOut, rows));
 #define SMF4_LAUNCH(COST, ROWS, NW, LF) \
-    hipLaunchKernelGGL((k_softmax_final4<COST, ROWS, NW>), grid4, dim3(NW * 64), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, LF)
+    MCN_LAUNCH((k_softmax_final4<COST, ROWS, NW>), grid4, dim3(NW * 64), 0, s, x, probs, part, numOut, numCases, chunks, labels, grad, coeff, LF)
 #define SMF4_PICK(COST, LF)                                     \
     if (rows == 512) SMF4_LAUNCH(COST, 512, 8, LF);             \
     else if (rows == 256 && nw == 8) SMF4_LAUNCH(COST, 256, 8, LF); \
@@ -671,7 +671,7 @@ static int softmax_final_launch(const float* x, float* probs, const float* part,
 #undef SMF4_PICK
 #undef SMF4_LAUNCH
     else
-        hipLaunchKernelGGL(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
+        MCN_LAUNCH(k_softmax_final, dim3(divup(numCases, SMF_COLS), divup(numOut, SMF_ROWS)), dim3(256), 0, s, x, probs, part, numOut,
                            numCases, chunks, labels, grad, coeff);
     return MCN_LAUNCH_CHECK("softmax");
 }
@@ -690,7 +690,7 @@ static int softmax_impl(const float* x, float* probs, const float* labels, float
     MCN_REQUIRE(chunks <= 65535, "softmax: too many outputs");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(divup(numCases, 64), chunks);
-    hipLaunchKernelGGL(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
+    MCN_LAUNCH(k_softmax_partial, grid, dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
     return softmax_final_launch(x, probs, (const float*)workspace, numOut, numCases, chunks, labels, grad, coeff, s);
 }
 // stage 2 alone, from partials the classifier layer's forward product left (mcn_gemm_bias_neuron_softmax_part)
@@ -719,7 +719,7 @@ MCN_API int mcn_softmax_logreg_cost_finish(float* labelLogProbs, float* correctP
     lf.correctProbs = correctProbs;
     lf.costOut = costOut;
     lf.tieCnt = (int*)state;
-    hipLaunchKernelGGL(k_logreg_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, lf, numCases);
+    MCN_LAUNCH(k_logreg_finish, dim3(1), dim3(256), 0, (hipStream_t)stream, lf, numCases);
     return MCN_LAUNCH_CHECK("logreg finish");
 }
 MCN_API int mcn_softmax_logreg_cost_supported(int numOut, int numCases) {
@@ -743,7 +743,7 @@ MCN_API int mcn_softmax_logreg_cost(const float* x, float* probs, const float* l
             mcn_set_error("softmaxLogregCost: workspace %zu < %zu bytes", workspaceBytes, need);
             return MCN_EWORKSPACE;
         }
-        hipLaunchKernelGGL(k_softmax_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
+        MCN_LAUNCH(k_softmax_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, x, (float*)workspace, numOut, numCases, chunks);
         stage1 = workspace;
     }
     MCN_REQUIRE(softmax_final4_usable(x, probs, (const float*)stage1, gradTarget, numOut, numCases), "softmaxLogregCost: pointers must be 16-byte aligned");
@@ -754,7 +754,7 @@ MCN_API int mcn_softmax_logreg_cost(const float* x, float* probs, const float* l
     lf.tieCnt = (int*)state;
     const int rc = softmax_final_launch(x, probs, (const float*)stage1, numOut, numCases, chunks, labels, gradTarget, coeff, s, &lf);
     if (rc != MCN_OK || !finish) return rc;
-    hipLaunchKernelGGL(k_logreg_finish, dim3(1), dim3(256), 0, s, lf, numCases);
+    MCN_LAUNCH(k_logreg_finish, dim3(1), dim3(256), 0, s, lf, numCases);
     return MCN_LAUNCH_CHECK("logreg finish");
 }
 MCN_API int mcn_softmax(const float* x, float* probs, int numOut, int numCases, void* workspace, size_t workspaceBytes, void* stream) {
@@ -863,8 +863,8 @@ MCN_API int mcn_logreg_cost(const float* labels, const float* probs, float* labe
     }
     MCN_REQUIRE(chunks <= 65535, "logregCost: too many outputs");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_logreg_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, probs, (float*)workspace, numOut, numCases);
-    hipLaunchKernelGGL(k_logreg_final, dim3(divup(numCases, SMF_COLS)), dim3(256), 0, s, labels, probs, (const float*)workspace,
+    MCN_LAUNCH(k_logreg_partial, dim3(divup(numCases, 64), chunks), dim3(256), 0, s, probs, (float*)workspace, numOut, numCases);
+    MCN_LAUNCH(k_logreg_final, dim3(divup(numCases, SMF_COLS)), dim3(256), 0, s, labels, probs, (const float*)workspace,
                        labelLogProbs, correctProbs, numOut, numCases, chunks, costOut);
     return MCN_LAUNCH_CHECK("logregCost");
 }
@@ -884,14 +884,14 @@ __global__ __launch_bounds__(256) void k_logreg_grads(const float* __restrict__ 
 MCN_API int mcn_logreg_softmax_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
                                     float coeff, void* stream) {
     MCN_REQUIRE(labels && probs && target && numOut > 0 && numCases > 0, "logregSoftmaxGrad: bad argument");
-    hipLaunchKernelGGL((k_logreg_grads<0>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
+    MCN_LAUNCH((k_logreg_grads<0>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
                        target, numOut, numCases, add, coeff);
     return MCN_LAUNCH_CHECK("logregSoftmaxGrad");
 }
 MCN_API int mcn_logreg_grad(const float* labels, const float* probs, float* target, int numOut, int numCases, int add,
                             float coeff, void* stream) {
     MCN_REQUIRE(labels && probs && target && numOut > 0 && numCases > 0, "logregGrad: bad argument");
-    hipLaunchKernelGGL((k_logreg_grads<1>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
+    MCN_LAUNCH((k_logreg_grads<1>), dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, labels, probs,
                        target, numOut, numCases, add, coeff);
     return MCN_LAUNCH_CHECK("logregGrad");
 }
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(256) void k_softmax_grad(const float* __restrict__ 
 }
 MCN_API int mcn_softmax_grad(const float* acts, const float* actsGrad, float* target, int numOut, int numCases, int add, void* stream) {
     MCN_REQUIRE(acts && actsGrad && target && numOut > 0 && numCases > 0, "softmaxGrad: bad argument");
-    hipLaunchKernelGGL(k_softmax_grad, dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, acts, actsGrad,
+    MCN_LAUNCH(k_softmax_grad, dim3(ew_blocks((size_t)numOut * numCases)), dim3(256), 0, (hipStream_t)stream, acts, actsGrad,
                        target, numOut, numCases, add);
     return MCN_LAUNCH_CHECK("softmaxGrad");
 }
@@ -1110,9 +1110,9 @@ static int l2sn_launch(int mode, const float* idens, const float* data, float* o
     const int rowsPerBlock = std::max(1, 512 / h);  // two gradient elements per thread
     const int gradBlocks = divup(numD, rowsPerBlock);
 #define L2SN_ARGS idens, data, out, numD, numCases, m, add, coeff, info, pairStats, costOut, extD, extL, extCount, rowsPerBlock, tile
-    if (mode == 0) hipLaunchKernelGGL((k_l2sn<0>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
-    else if (mode == 1) hipLaunchKernelGGL((k_l2sn<1>), dim3(gradBlocks), dim3(256), lds, s, L2SN_ARGS);
-    else hipLaunchKernelGGL((k_l2sn<2>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+    if (mode == 0) MCN_LAUNCH((k_l2sn<0>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
+    else if (mode == 1) MCN_LAUNCH((k_l2sn<1>), dim3(gradBlocks), dim3(256), lds, s, L2SN_ARGS);
+    else MCN_LAUNCH((k_l2sn<2>), dim3(1), dim3(256), lds, s, L2SN_ARGS);
 #undef L2SN_ARGS
     return MCN_LAUNCH_CHECK("l2sn");
 }
@@ -1151,7 +1151,7 @@ MCN_API int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int n
     MCN_REQUIRE(data && dataTarget && pairStats && info && numD > 0 && numCases > 0, "l2snGradFromStats: bad argument");
     MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");
     const size_t elems = (size_t)numD * (numCases / 2);
-    hipLaunchKernelGGL(k_l2sn_grad_stats, dim3((unsigned)divup_sz(elems, 256)), dim3(256), 0, (hipStream_t)stream, data, dataTarget, numD,
+    MCN_LAUNCH(k_l2sn_grad_stats, dim3((unsigned)divup_sz(elems, 256)), dim3(256), 0, (hipStream_t)stream, data, dataTarget, numD,
                        numCases, pairStats, info, add, coeff);
     return MCN_LAUNCH_CHECK("l2snGradFromStats");
 }
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(256) void k_l2reg_cost(const float* __restrict__ gr
 }
 MCN_API int mcn_l2reg_cost(const float* ground, const float* data, float* output, int numD, int numCases, double* costOut, void* stream) {
     MCN_REQUIRE(ground && data && output && numD > 0 && numCases > 0, "l2regCost: bad argument");
-    hipLaunchKernelGGL(k_l2reg_cost, dim3(1), dim3(256), 0, (hipStream_t)stream, ground, data, output, numD, numCases, costOut);
+    MCN_LAUNCH(k_l2reg_cost, dim3(1), dim3(256), 0, (hipStream_t)stream, ground, data, output, numD, numCases, costOut);
     return MCN_LAUNCH_CHECK("l2regCost");
 }
 __global__ __launch_bounds__(256) void k_l2reg_grad(const float* ground, const float* data, float* target, size_t n, int add, float coeff) {
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_l2reg_grad(const float* ground, const f
 MCN_API int mcn_l2reg_grad(const float* ground, const float* data, float* target, int numD, int numCases, int add, float coeff, void* stream) {
     MCN_REQUIRE(ground && data && target && numD > 0 && numCases > 0, "l2regGrad: bad argument");
     const size_t n = (size_t)numD * numCases;
-    hipLaunchKernelGGL(k_l2reg_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, ground, data, target, n, add, coeff);
+    MCN_LAUNCH(k_l2reg_grad, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, ground, data, target, n, add, coeff);
     return MCN_LAUNCH_CHECK("l2regGrad");
 }
 
@@ -1229,9 +1229,9 @@ MCN_API int mcn_sgd_update(float* W, float* inc, const float* grad, size_t n, fl
     hipStream_t s = (hipStream_t)stream;
     const float wcEps = -wc * eps;
     if (n % 4 == 0 && al16(W) && al16(inc) && (!useGrad || al16(grad)))
-        hipLaunchKernelGGL(k_sgd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (f32x4*)W, (f32x4*)inc, (const f32x4*)grad, n / 4, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
+        MCN_LAUNCH(k_sgd4, dim3(ew_blocks(n / 4)), dim3(256), 0, s, (f32x4*)W, (f32x4*)inc, (const f32x4*)grad, n / 4, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_sgd, dim3(ew_blocks(n)), dim3(256), 0, s, W, inc, grad, n, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
+        MCN_LAUNCH(k_sgd, dim3(ew_blocks(n)), dim3(256), 0, s, W, inc, grad, n, mom, wcEps, useGrad, wc > 0 ? 1 : 0);
     return MCN_LAUNCH_CHECK("sgdUpdate");
 }
 
@@ -1303,7 +1303,7 @@ MCN_API int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devic
 }
 MCN_API int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream) {
     MCN_REQUIRE(devicePlan && count > 0 && numBlocks > 0, "sgdUpdatePlanned: bad argument");
-    hipLaunchKernelGGL(k_sgd_planned, dim3(numBlocks), dim3(256), 0, (hipStream_t)stream, (const SgdRec*)devicePlan, count);
+    MCN_LAUNCH(k_sgd_planned, dim3(numBlocks), dim3(256), 0, (hipStream_t)stream, (const SgdRec*)devicePlan, count);
     return MCN_LAUNCH_CHECK("sgdUpdatePlanned");
 }
 
@@ -1432,8 +1432,8 @@ static int fisher2_common(const float* labels, const float* data, int numD, int 
     }
     float* E = ws;
     float* stats = ws + (size_t)2 * N * N + N;
-    hipLaunchKernelGGL(k_fisher2_dist, dim3(divup(N, 256), N), dim3(256), 0, s, data, E, numD, N);
-    hipLaunchKernelGGL(k_fisher2_stats, dim3(1), dim3(1024), 0, s, labels, (const float*)E, stats, N, alpha, costOut);
+    MCN_LAUNCH(k_fisher2_dist, dim3(divup(N, 256), N), dim3(256), 0, s, data, E, numD, N);
+    MCN_LAUNCH(k_fisher2_stats, dim3(1), dim3(1024), 0, s, labels, (const float*)E, stats, N, alpha, costOut);
     return MCN_LAUNCH_CHECK("fisher2");
 }
 MCN_API int mcn_fisher2_cost(const float* labels, const float* data, int numD, int numCases, float alpha, double* costOut,
@@ -1451,8 +1451,8 @@ MCN_API int mcn_fisher2_grad(const float* labels, const float* data, float* targ
     float* S = E + (size_t)N * N;
     float* r = S + (size_t)N * N;
     float* stats = r + N;
-    hipLaunchKernelGGL(k_fisher2_q, dim3(N), dim3(256), 0, s, labels, (const float*)E, (const float*)stats, S, r, N, alpha);
-    hipLaunchKernelGGL(k_fisher2_grad, dim3(divup(N, 256), numD), dim3(256), 0, s, data, (const float*)S, (const float*)r, target, numD, N, add,
+    MCN_LAUNCH(k_fisher2_q, dim3(N), dim3(256), 0, s, labels, (const float*)E, (const float*)stats, S, r, N, alpha);
+    MCN_LAUNCH(k_fisher2_grad, dim3(divup(N, 256), numD), dim3(256), 0, s, data, (const float*)S, (const float*)r, target, numD, N, add,
                        coeff);
     return MCN_LAUNCH_CHECK("fisher2Grad");
 }

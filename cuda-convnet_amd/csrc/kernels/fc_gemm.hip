@@ -476,8 +476,8 @@ int fc_nn_lds_launch(const float* A, const float* B, const float* bias, float* C
     MCN_REQUIRE(grid.y <= 65535, "gemm: grid too large");
     p.tick = mcn_take_tick(s);  // (after the last check: a tick taken is a tick sent)
     // 160-row chunks when they waste nothing (K = 160), else 128
-    if (K % 160 == 0 || (K < 160 && K > 128)) hipLaunchKernelGGL((k_fc_nn_lds<10>), grid, dim3(256), 160 * 128 * 4, s, p);
-    else hipLaunchKernelGGL((k_fc_nn_lds<8>), grid, dim3(256), 128 * 128 * 4, s, p);
+    if (K % 160 == 0 || (K < 160 && K > 128)) MCN_LAUNCH((k_fc_nn_lds<10>), grid, dim3(256), 160 * 128 * 4, s, p);
+    else MCN_LAUNCH((k_fc_nn_lds<8>), grid, dim3(256), 128 * 128 * 4, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc nn)");
 }
 
@@ -488,9 +488,9 @@ int fc_nt_lds_launch(const float* A, const float* B, float* C, int M, int N, int
     dim3 grid(divup(M, 64), divup(N, 16 * nt));
     MCN_REQUIRE(grid.y <= 65535, "gemm: grid too large");
     const size_t lds = (size_t)16 * nt * 128 * 4;
-    if (nt == 10) hipLaunchKernelGGL((k_fc_nt_lds<10>), grid, dim3(256), lds, s, p);
-    else if (nt == 8) hipLaunchKernelGGL((k_fc_nt_lds<8>), grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL((k_fc_nt_lds<4>), grid, dim3(256), lds, s, p);
+    if (nt == 10) MCN_LAUNCH((k_fc_nt_lds<10>), grid, dim3(256), lds, s, p);
+    else if (nt == 8) MCN_LAUNCH((k_fc_nt_lds<8>), grid, dim3(256), lds, s, p);
+    else MCN_LAUNCH((k_fc_nt_lds<4>), grid, dim3(256), lds, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc nt)");
 }
 
@@ -509,11 +509,11 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     dim3 grid(divup(N, 64), divup(M, 16 * pl.mg), pl.splits);
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     p.tick = mcn_take_tick(s);
-    if (pl.mg == 5) hipLaunchKernelGGL((k_fc_tn_split<5, 6>), grid, dim3(256), 2 * 20 * 64 * 16, s, p);
-    else hipLaunchKernelGGL((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
+    if (pl.mg == 5) MCN_LAUNCH((k_fc_tn_split<5, 6>), grid, dim3(256), 2 * 20 * 64 * 16, s, p);
+    else MCN_LAUNCH((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
     int rc = MCN_LAUNCH_CHECK("gemm (fc tn)");
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
+    MCN_LAUNCH(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc tn reduce)");
 }
 
@@ -721,8 +721,8 @@ int fc_fprop_multi_launch(const float* const* W, const float* const* X, const in
     MCN_REQUIRE(grid.y <= 65535, "fcFpropMulti: grid too large");
     // a wave's whole share in two register sets of 9 steps when it fits (fc5: 139 steps / 8 waves = 18): every load is in
     // flight before the first MFMA, one round trip per wave; longer reductions walk batches of 6
-    if ((p.totalSteps + 7) / 8 <= 18) hipLaunchKernelGGL((k_fc_fprop_multi<9>), grid, dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((k_fc_fprop_multi<6>), grid, dim3(512), 0, s, p);
+    if ((p.totalSteps + 7) / 8 <= 18) MCN_LAUNCH((k_fc_fprop_multi<9>), grid, dim3(512), 0, s, p);
+    else MCN_LAUNCH((k_fc_fprop_multi<6>), grid, dim3(512), 0, s, p);
     return MCN_LAUNCH_CHECK("fcFpropMulti");
 }
 
@@ -756,8 +756,8 @@ int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi
     p.tick = mcn_take_tick(s);
     // up to 160 outputs (fc5): the whole reduction in two register sets of 20 steps, every load in flight before the first
     // MFMA (two round trips instead of four: 0.2475 -> 0.2446 ms per DeepID2 step); longer reductions walk batches of 10
-    if ((K + 3) / 4 <= 40) hipLaunchKernelGGL((k_fc_bprop_multi<20>), grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((k_fc_bprop_multi<10>), grid, dim3(64), 0, s, p);
+    if ((K + 3) / 4 <= 40) MCN_LAUNCH((k_fc_bprop_multi<20>), grid, dim3(64), 0, s, p);
+    else MCN_LAUNCH((k_fc_bprop_multi<10>), grid, dim3(64), 0, s, p);
     return MCN_LAUNCH_CHECK("fcBpropActsMulti");
 }
 
@@ -848,7 +848,7 @@ int fc_wgrad_multi_launch(const float* dY, const float* const* X, float* const* 
     for (int i = count; i < FCM_MAXSEG; i++) p.steps[i] = 1 << 30;
     p.dY = dY; p.M = M; p.N = N;
     dim3 grid(divup(M, 32), tiles);
-    hipLaunchKernelGGL((k_fc_wgrad_multi<8>), grid, dim3(64), 0, s, p);
+    MCN_LAUNCH((k_fc_wgrad_multi<8>), grid, dim3(64), 0, s, p);
     return MCN_LAUNCH_CHECK("fcBpropWeightsMulti");
 }
 

@@ -452,32 +452,32 @@ static int gemm_impl(const float* A, const float* B, const float* bias, float* C
         dim3 grid(divup(N, 64 * pl.nv), divup(M, 16 * pl.mv), pl.splits);
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
         const size_t lds = (size_t)std::max(1, pl.nw / 2) * pl.mv * pl.nv * 4 * 64 * 16;
-        if (pl.mv == 2 && pl.nv == 2) hipLaunchKernelGGL((k_gemm_nn<2, 2, 2>), grid, block, lds, s, p);
-        else if (pl.mv == 2) hipLaunchKernelGGL((k_gemm_nn<2, 1, 2>), grid, block, lds, s, p);
-        else if (pl.nv == 2) hipLaunchKernelGGL((k_gemm_nn<1, 2, 2>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((k_gemm_nn<1, 1, 2>), grid, block, lds, s, p);
+        if (pl.mv == 2 && pl.nv == 2) MCN_LAUNCH((k_gemm_nn<2, 2, 2>), grid, block, lds, s, p);
+        else if (pl.mv == 2) MCN_LAUNCH((k_gemm_nn<2, 1, 2>), grid, block, lds, s, p);
+        else if (pl.nv == 2) MCN_LAUNCH((k_gemm_nn<1, 2, 2>), grid, block, lds, s, p);
+        else MCN_LAUNCH((k_gemm_nn<1, 1, 2>), grid, block, lds, s, p);
     } else if (ta) {
         dim3 grid(divup(N, 64), divup(M, 64), pl.splits);
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
         const size_t lds = (size_t)std::max(1, pl.nw / 2) * 16 * 64 * 16;
-        hipLaunchKernelGGL((k_gemm_tn<1, 4>), grid, block, lds, s, p);
+        MCN_LAUNCH((k_gemm_tn<1, 4>), grid, block, lds, s, p);
     } else {
         dim3 grid(divup(N, 16 * pl.nv), divup(M, 16 * pl.mv), pl.splits);
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
         const size_t lds = (size_t)std::max(1, pl.nw / 2) * pl.mv * pl.nv * 64 * 16;
         switch (pl.nv) {
-            case 5: hipLaunchKernelGGL((k_gemm_nt<1, 5, 2>), grid, block, lds, s, p); break;
-            case 4: hipLaunchKernelGGL((k_gemm_nt<1, 4, 2>), grid, block, lds, s, p); break;
-            case 3: hipLaunchKernelGGL((k_gemm_nt<1, 3, 2>), grid, block, lds, s, p); break;
-            case 2: hipLaunchKernelGGL((k_gemm_nt<1, 2, 2>), grid, block, lds, s, p); break;
-            default: hipLaunchKernelGGL((k_gemm_nt<1, 1, 2>), grid, block, lds, s, p); break;
+            case 5: MCN_LAUNCH((k_gemm_nt<1, 5, 2>), grid, block, lds, s, p); break;
+            case 4: MCN_LAUNCH((k_gemm_nt<1, 4, 2>), grid, block, lds, s, p); break;
+            case 3: MCN_LAUNCH((k_gemm_nt<1, 3, 2>), grid, block, lds, s, p); break;
+            case 2: MCN_LAUNCH((k_gemm_nt<1, 2, 2>), grid, block, lds, s, p); break;
+            default: MCN_LAUNCH((k_gemm_nt<1, 1, 2>), grid, block, lds, s, p); break;
         }
     }
     int rc = MCN_LAUNCH_CHECK("gemm");
     if (rc) return rc;
     if (pl.splits > 1) {
         const size_t total = (size_t)M * N;
-        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)divup_sz(total, 1024)), dim3(256), 0, s, p);
+        MCN_LAUNCH(k_gemm_reduce, dim3((unsigned)divup_sz(total, 1024)), dim3(256), 0, s, p);
         rc = MCN_LAUNCH_CHECK("gemm reduce");
     }
     return rc;

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_shift_gather(const float* __restrict__ 
 }
 
 #define IMG_LAUNCH(kernel, rows, ...) \
-    hipLaunchKernelGGL(kernel, dim3(elem_blocks(rows, numImages)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+    MCN_LAUNCH(kernel, dim3(elem_blocks(rows, numImages)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 
 MCN_API int mcn_bed_of_nails(const float* images, float* target, int numImages, int numChannels, int imgSizeY, int imgSizeX, int startX,
                              int strideX, int outputsY, int outputsX, float scaleTargets, float scaleOutput, void* stream) {

@@ -210,11 +210,11 @@ MCN_API int mcn_local_pool(const float* images, float* target, int numImages, in
     dim3 grid(blocks_for(rows, numImages, v4 ? 4 : 1));
 #define POOL_ARGS images, target, numImages, numFilters, imgSizeY, imgSizeX, subsX, startX, strideX, outputsY, outputsX
     if (v4) {
-        if (mode == 0) hipLaunchKernelGGL((k_local_pool<4, 0>), grid, dim3(256), 0, s, POOL_ARGS);
-        else hipLaunchKernelGGL((k_local_pool<4, 1>), grid, dim3(256), 0, s, POOL_ARGS);
+        if (mode == 0) MCN_LAUNCH((k_local_pool<4, 0>), grid, dim3(256), 0, s, POOL_ARGS);
+        else MCN_LAUNCH((k_local_pool<4, 1>), grid, dim3(256), 0, s, POOL_ARGS);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((k_local_pool<1, 0>), grid, dim3(256), 0, s, POOL_ARGS);
-        else hipLaunchKernelGGL((k_local_pool<1, 1>), grid, dim3(256), 0, s, POOL_ARGS);
+        if (mode == 0) MCN_LAUNCH((k_local_pool<1, 0>), grid, dim3(256), 0, s, POOL_ARGS);
+        else MCN_LAUNCH((k_local_pool<1, 1>), grid, dim3(256), 0, s, POOL_ARGS);
     }
 #undef POOL_ARGS
     return MCN_LAUNCH_CHECK("localPool");
@@ -232,14 +232,14 @@ static int pool_undo_impl(const float* images, const float* grads, const float* 
     dim3 grid(blocks_for(rows, numImages, v4 ? 4 : 1));
 #define UNDO_ARGS images, grads, maxActs, target, numImages, numFilters, imgY, imgX, subsX, startX, strideX, outY, outX, sT, sO, neuron, na, nb
     if (mode == 1) {
-        if (v4) hipLaunchKernelGGL((k_pool_undo<4, 1, false>), grid, dim3(256), 0, s, UNDO_ARGS);
-        else hipLaunchKernelGGL((k_pool_undo<1, 1, false>), grid, dim3(256), 0, s, UNDO_ARGS);
+        if (v4) MCN_LAUNCH((k_pool_undo<4, 1, false>), grid, dim3(256), 0, s, UNDO_ARGS);
+        else MCN_LAUNCH((k_pool_undo<1, 1, false>), grid, dim3(256), 0, s, UNDO_ARGS);
     } else if (neuron >= 0) {
-        if (v4) hipLaunchKernelGGL((k_pool_undo<4, 0, true>), grid, dim3(256), 0, s, UNDO_ARGS);
-        else hipLaunchKernelGGL((k_pool_undo<1, 0, true>), grid, dim3(256), 0, s, UNDO_ARGS);
+        if (v4) MCN_LAUNCH((k_pool_undo<4, 0, true>), grid, dim3(256), 0, s, UNDO_ARGS);
+        else MCN_LAUNCH((k_pool_undo<1, 0, true>), grid, dim3(256), 0, s, UNDO_ARGS);
     } else {
-        if (v4) hipLaunchKernelGGL((k_pool_undo<4, 0, false>), grid, dim3(256), 0, s, UNDO_ARGS);
-        else hipLaunchKernelGGL((k_pool_undo<1, 0, false>), grid, dim3(256), 0, s, UNDO_ARGS);
+        if (v4) MCN_LAUNCH((k_pool_undo<4, 0, false>), grid, dim3(256), 0, s, UNDO_ARGS);
+        else MCN_LAUNCH((k_pool_undo<1, 0, false>), grid, dim3(256), 0, s, UNDO_ARGS);
     }
 #undef UNDO_ARGS
     return MCN_LAUNCH_CHECK("poolUndo");
@@ -282,11 +282,11 @@ static int rnorm_impl(const float* images, const float* md, float* denoms, float
     dim3 grid(blocks_for(rows, numImages, v4 ? 4 : 1));
 #define RN_ARGS images, md, denoms, target, numImages, numFilters, imgY, imgX, size, addScale, powScale, blocked
     if (cross) {
-        if (v4) hipLaunchKernelGGL((k_rnorm<4, true>), grid, dim3(256), 0, s, RN_ARGS);
-        else hipLaunchKernelGGL((k_rnorm<1, true>), grid, dim3(256), 0, s, RN_ARGS);
+        if (v4) MCN_LAUNCH((k_rnorm<4, true>), grid, dim3(256), 0, s, RN_ARGS);
+        else MCN_LAUNCH((k_rnorm<1, true>), grid, dim3(256), 0, s, RN_ARGS);
     } else {
-        if (v4) hipLaunchKernelGGL((k_rnorm<4, false>), grid, dim3(256), 0, s, RN_ARGS);
-        else hipLaunchKernelGGL((k_rnorm<1, false>), grid, dim3(256), 0, s, RN_ARGS);
+        if (v4) MCN_LAUNCH((k_rnorm<4, false>), grid, dim3(256), 0, s, RN_ARGS);
+        else MCN_LAUNCH((k_rnorm<1, false>), grid, dim3(256), 0, s, RN_ARGS);
     }
 #undef RN_ARGS
     return MCN_LAUNCH_CHECK("responseNorm");
@@ -301,17 +301,17 @@ static int rnorm_undo_impl(const float* outGrads, const float* denoms, const flo
     const long long rows = (long long)numFilters * imgY * imgX;
     const size_t total = (size_t)rows * numImages;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_rnorm_undo_prelims, dim3((unsigned)std::min<size_t>(divup_sz(total, 256), 8192)), dim3(256), 0, s,
+    MCN_LAUNCH(k_rnorm_undo_prelims, dim3((unsigned)std::min<size_t>(divup_sz(total, 256), 8192)), dim3(256), 0, s,
                        acts, denoms, outGrads, total, -2 * addScale * powScale);
     const bool v4 = vec_ok(numImages, {outGrads, denoms, inputs, acts, target});
     dim3 grid(blocks_for(rows, numImages, v4 ? 4 : 1));
 #define RU_ARGS outGrads, denoms, inputs, acts, target, numImages, numFilters, imgY, imgX, size, powScale, blocked, sT, sO
     if (cross) {
-        if (v4) hipLaunchKernelGGL((k_rnorm_undo<4, true>), grid, dim3(256), 0, s, RU_ARGS);
-        else hipLaunchKernelGGL((k_rnorm_undo<1, true>), grid, dim3(256), 0, s, RU_ARGS);
+        if (v4) MCN_LAUNCH((k_rnorm_undo<4, true>), grid, dim3(256), 0, s, RU_ARGS);
+        else MCN_LAUNCH((k_rnorm_undo<1, true>), grid, dim3(256), 0, s, RU_ARGS);
     } else {
-        if (v4) hipLaunchKernelGGL((k_rnorm_undo<4, false>), grid, dim3(256), 0, s, RU_ARGS);
-        else hipLaunchKernelGGL((k_rnorm_undo<1, false>), grid, dim3(256), 0, s, RU_ARGS);
+        if (v4) MCN_LAUNCH((k_rnorm_undo<4, false>), grid, dim3(256), 0, s, RU_ARGS);
+        else MCN_LAUNCH((k_rnorm_undo<1, false>), grid, dim3(256), 0, s, RU_ARGS);
     }
 #undef RU_ARGS
     return MCN_LAUNCH_CHECK("responseNormUndo");

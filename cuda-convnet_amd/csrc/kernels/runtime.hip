@@ -44,7 +44,7 @@ static void tick_send_now(int why = 0) {
         (void)reg;
         g_tickSent[why]++;
     }
-    hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value);
+    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value);
     t_tick.flag = nullptr;
 }
 McnTick mcn_take_tick(hipStream_t stream) {
@@ -58,6 +58,7 @@ McnTick mcn_take_tick(hipStream_t stream) {
 }
 
 static thread_local size_t t_launches = 0;
+thread_local uint64_t t_mcnLaunchNs = 0;
 int mcn_launch_check(const char* what) {
     t_launches++;
     tick_send_now();  // (a tick the launch above did not carry: right behind it)
@@ -71,6 +72,7 @@ int mcn_launch_check(const char* what) {
     return mcn_check_hip(hipGetLastError(), what);
 }
 MCN_API size_t mcn_launch_count(void) { return t_launches; }
+MCN_API uint64_t mcn_launch_ns(void) { return t_mcnLaunchNs; }
 
 MCN_API const char* mcn_last_error(void) { return g_err; }
 
@@ -119,8 +121,8 @@ MCN_API int mcn_tile_minibatches(const float* src, float* dst, int rows, size_t 
     const bool vec = minibatch % 4 == 0 && numCases % 4 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
     const long cols = vec ? numCases / 4 : numCases;
     dim3 grid((unsigned)((cols + 255) / 256), (unsigned)std::min(rows, 4096));
-    if (vec) hipLaunchKernelGGL((k_tile_minibatches<4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
-    else hipLaunchKernelGGL((k_tile_minibatches<1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
+    if (vec) MCN_LAUNCH((k_tile_minibatches<4>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
+    else MCN_LAUNCH((k_tile_minibatches<1>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, rows, numCases, minibatch);
     return MCN_LAUNCH_CHECK("tileMinibatches");
 }
 MCN_API int mcn_stream_create(void** stream) {
@@ -231,7 +233,7 @@ MCN_API int mcn_tick_free(int* flag) { return flag ? mcn_check_hip(hipHostFree(f
 MCN_API int mcn_stream_tick(int* flag, int value, void* stream) {
     MCN_REQUIRE(flag, "streamTick: null pointer");
     tick_send_now(3);  // (an armed one first: ticks stay in order)
-    hipLaunchKernelGGL(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value);
+    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value);
     return mcn_check_hip(hipGetLastError(), "streamTick");
 }
 

@@ -75,14 +75,14 @@ MCN_API int mcn_gather_channels(const float* images, int imgStride, const int* c
     MCN_REQUIRE(images && colorIndices && target && numImages > 0 && imgStride >= numImages && numImgColors > 0 && numIndices > 0 && imgPixels > 0,
                 "gatherChannels: bad argument");
     MCN_REQUIRE(images != target, "gatherChannels: not in place");
-    hipLaunchKernelGGL(k_gather_channels, dim3(blocks_for((long long)numIndices * imgPixels * numImages)), dim3(256), 0, (hipStream_t)stream,
+    MCN_LAUNCH(k_gather_channels, dim3(blocks_for((long long)numIndices * imgPixels * numImages)), dim3(256), 0, (hipStream_t)stream,
                        images, imgStride, colorIndices, target, numImages, numImgColors, numIndices, imgPixels);
     return MCN_LAUNCH_CHECK("gatherChannels");
 }
 MCN_API int mcn_invert_channel_indices(const int* colorIndices, int* inverse, int numImgColors, int overSample, void* stream) {
     MCN_REQUIRE(colorIndices && inverse && numImgColors > 0 && overSample > 0, "invertChannelIndices: bad argument");
     const int total = numImgColors * overSample;
-    hipLaunchKernelGGL(k_invert_channel_indices, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, colorIndices, inverse, numImgColors,
+    MCN_LAUNCH(k_invert_channel_indices, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, colorIndices, inverse, numImgColors,
                        total);
     return MCN_LAUNCH_CHECK("invertChannelIndices");
 }
@@ -91,7 +91,7 @@ MCN_API int mcn_scatter_channels_sum(const float* gathered, const int* inverse, 
     MCN_REQUIRE(gathered && inverse && target && numImages > 0 && numImgColors > 0 && overSample > 0 && imgPixels > 0,
                 "scatterChannelsSum: bad argument");
     MCN_REQUIRE(gathered != target, "scatterChannelsSum: not in place");
-    hipLaunchKernelGGL(k_scatter_channels_sum, dim3(blocks_for((long long)numImgColors * imgPixels * numImages)), dim3(256), 0,
+    MCN_LAUNCH(k_scatter_channels_sum, dim3(blocks_for((long long)numImgColors * imgPixels * numImages)), dim3(256), 0,
                        (hipStream_t)stream, gathered, inverse, target, numImages, numImgColors, overSample, imgPixels, scaleTargets, scaleOutput);
     return MCN_LAUNCH_CHECK("scatterChannelsSum");
 }

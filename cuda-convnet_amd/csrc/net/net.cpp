@@ -18,6 +18,7 @@ void chk(int rc, const char* what) {
 
 // host time spent in cross-stream synchronisation calls (reported as host.events by runSteps)
 thread_local double g_eventCallMs = 0;
+thread_local double g_blockedMs = 0;
 int timedEventRecord(void* e, void* s) {
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = mcn_event_record(e, s);
@@ -1555,7 +1556,14 @@ ConvNet::~ConvNet() {
 // Fused epilogues, decided once from the graph (no counterpart in the reference, which launches
 // bias add, neuron and pool-undo / neuron-gradient as separate kernels: layer.cu:249, :453-461, :734).
 void ConvNet::buildFusions() {
-    if (!_fusion) return;
+    if (!_fusion) {  // (MCN_NO_FUSION: the per-input tables of the FC layers still have to exist)
+        for (auto& up : _layers)
+            if (auto* fc = dynamic_cast<FCLayer*>(up.get())) {
+                fc->planMulti();
+                fc->multiShapes = false;
+            }
+        return;
+    }
     for (auto& up : _layers) {
         // forward: conv/local/fc with ONE input whose only consumer is a neuron layer sharing its activity matrix
         if (auto* w = dynamic_cast<WeightLayer*>(up.get())) {
@@ -1908,8 +1916,12 @@ long Submitter::push(std::function<void()> fn) {
 }
 
 void Submitter::wait(long ticket) {
-    for (int spin = 0; _done.load(std::memory_order_acquire) < ticket; spin++)
-        if (spin > 64) std::this_thread::yield();
+    if (_done.load(std::memory_order_acquire) < ticket) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spin = 0; _done.load(std::memory_order_acquire) < ticket; spin++)
+            if (spin > 64) std::this_thread::yield();
+        g_blockedMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     std::exception_ptr e;
     {
         std::lock_guard<std::mutex> lk(_mutex);
@@ -2100,9 +2112,17 @@ void ConvNet::flushSideWork(size_t count) {
     }
     _side.push([this, forkEvent, tick, fns] {
         t_stream = 1;
+        const auto t0 = std::chrono::steady_clock::now();
         if (forkEvent) chk(timedStreamWait(_gradStream, forkEvent), "wait event");
         else awaitTick(tick);
+        const auto t1 = std::chrono::steady_clock::now();
+        const uint64_t l0 = mcn_launch_ns();
+        const size_t c0 = mcn_launch_count();
         for (auto& fn : *fns) fn();
+        _sidePollNs += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+        _sideWorkNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+        _sideLaunchNs += (long)(mcn_launch_ns() - l0);
+        _sideLaunches += (long)(mcn_launch_count() - c0);
     });
 }
 

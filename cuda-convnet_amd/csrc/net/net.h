@@ -38,6 +38,7 @@ struct NetError : std::runtime_error {
 };
 void chk(int rc, const char* what);
 extern thread_local double g_eventCallMs;
+extern thread_local double g_blockedMs;  // this thread waiting for another submitting thread (Submitter::wait)
 int timedEventRecord(void* event, void* stream);
 int timedStreamWait(void* stream, void* event);  // throws NetError carrying mcn_last_error()
 
@@ -794,6 +795,9 @@ class ConvNet {
     int _tickSeq = 0;
     int* _tickFlagSide = nullptr;  // side stream -> exchange thread (gradient buckets written by the side stream)
     int _tickSeqSide = 0;
+    // host-side accounting of the side thread (runSteps reports it as host.side.*): ns inside launch calls, launches, ns polling
+    // for fork ticks / events, ns running closures
+    std::atomic<long> _sideLaunchNs{0}, _sideLaunches{0}, _sidePollNs{0}, _sideWorkNs{0};
     bool _commTicks = false;       // the exchange thread polls ticks instead of queueing event waits
     void awaitTick(int tick, volatile int* flag = nullptr);
     std::mutex _commMutex;  // gradient exchange calls may come from either submitting thread

@@ -120,8 +120,13 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
     _phases = profile == 2;
     const int nm = _dp->numMinibatches();
     long cases = 0;
+    joinGradWork();  // (nothing of an earlier work item on the side thread: its accounting starts at zero)
     const auto t0 = std::chrono::steady_clock::now();
     g_eventCallMs = 0;
+    g_blockedMs = 0;
+    const uint64_t launchNs0 = mcn_launch_ns();
+    const size_t launches0 = mcn_launch_count();
+    _sideLaunchNs = _sideLaunches = _sidePollNs = _sideWorkNs = 0;
     try {
         for (int s = 0; s < numSteps; s++) {
             if (!test && !profile) {
@@ -148,6 +153,21 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
         res.profile["host.enqueue"].ms = enq;
         res.profile["host.events"].count = numSteps;
         res.profile["host.events"].ms = g_eventCallMs;
+        // where the submitting threads' time went (bench.py host_breakdown): the main thread inside the runtime's launch call,
+        // blocked until the side thread had issued what it was given, in event / tick calls; the side thread polling for
+        // fork ticks and running its closures
+        auto put = [&](const char* k, double ms, long count) {
+            res.profile[k].count = count;
+            res.profile[k].ms = ms;
+        };
+        const double launchMs = (double)(mcn_launch_ns() - launchNs0) * 1e-6;
+        put("host.main.launch_calls", launchMs, (long)(mcn_launch_count() - launches0));
+        put("host.main.blocked_on_side_thread", g_blockedMs, numSteps);
+        put("host.main.event_and_tick_calls", g_eventCallMs, numSteps);
+        put("host.main.graph_walk_and_other", enq - launchMs - g_blockedMs - g_eventCallMs, numSteps);
+        put("host.side.launch_calls", _sideLaunchNs.load() * 1e-6, _sideLaunches.load());
+        put("host.side.polling_fork_ticks", _sidePollNs.load() * 1e-6, numSteps);
+        put("host.side.closures_total", _sideWorkNs.load() * 1e-6, numSteps);
     } catch (...) {
         _profiling = _phases = false;
         throw;

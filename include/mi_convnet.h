@@ -29,6 +29,7 @@
 #define MI_CONVNET_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -51,6 +52,9 @@ enum mcn_neuron {
 const char* mcn_last_error(void);
 /* kernel launches this thread has made through the library so far (profilers use it to drop spans that launched nothing) */
 size_t mcn_launch_count(void);
+/* ... and the host nanoseconds this thread has spent inside the runtime's kernel-launch call (submission cost, as opposed
+   to time a submitting thread spends blocked; no counterpart in the reference, which never measures its host side) */
+uint64_t mcn_launch_ns(void);
 int mcn_device_count(int* count);
 int mcn_set_device(int device);
 int mcn_alloc(void** ptr, size_t bytes);
