@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, 'libmiconvnet.so')
 _CTYPES = {
     'int': C.c_int, 'float': C.c_float, 'size_t': C.c_size_t, 'void*': C.c_void_p, 'void**': C.POINTER(C.c_void_p),
     'const void*': C.c_void_p, 'float*': C.c_void_p, 'const float*': C.c_void_p, 'double*': C.c_void_p,
-    'int*': C.POINTER(C.c_int), 'int**': C.POINTER(C.c_void_p), 'const int*': C.c_void_p, 'const float* const*': C.c_void_p, 'float* const*': C.c_void_p, 'const mcn_sgd_item*': C.c_void_p, 'const mcn_row_sum_item*': C.c_void_p, 'char*': C.c_char_p, 'const char*': C.c_char_p,
+    'int*': C.POINTER(C.c_int), 'int**': C.POINTER(C.c_void_p), 'const int*': C.c_void_p, 'const float* const*': C.c_void_p, 'float* const*': C.c_void_p, 'const mcn_sgd_item*': C.c_void_p, 'const mcn_row_sum_item*': C.c_void_p, 'const mcn_sgd_partials*': C.c_void_p, 'char*': C.c_char_p, 'const char*': C.c_char_p,
 }
 
 
@@ -34,7 +34,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     protos = {}
-    for m in re.finditer(r'(?:^|\n)\s*(const char\*|int|size_t)\s+(mcn_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
+    for m in re.finditer(r'(?:^|\n)\s*(const char\*|int|size_t|uint64_t)\s+(mcn_\w+)\s*\(([^;{]*?)\)\s*;', src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), ' '.join(m.group(3).split())
         parsed = []
         if args and args != 'void':
@@ -58,7 +58,7 @@ class Lib:
         self.protos = parse_header()
         for name, (ret, args) in self.protos.items():
             fn = getattr(self.dll, name)  # AttributeError if the symbol is not exported
-            fn.restype = {'int': C.c_int, 'size_t': C.c_size_t, 'const char*': C.c_char_p}[ret]
+            fn.restype = {'int': C.c_int, 'size_t': C.c_size_t, 'uint64_t': C.c_uint64, 'const char*': C.c_char_p}[ret]
             fn.argtypes = [_CTYPES[t] for t, _ in args]
 
     def raw(self, name):

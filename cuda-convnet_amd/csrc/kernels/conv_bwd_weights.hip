@@ -529,8 +529,9 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
                                          size_t workspaceBytes, int numImages, int imgStride, int imgSizeY,
                                          int imgSizeX, int numImgColors, int numFilters, int filterSize,
                                          int numModulesY, int numModulesX, int paddingStart, int moduleStride,
-                                         int numGroups, float scaleTargets, float scaleOutput, void* stream) {
-    int rc = weight_acts_check(images, hidActs, grad, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                                         int numGroups, float scaleTargets, float scaleOutput, void* stream, int* chunksOut = nullptr) {
+    // chunksOut: first stage only -- the partials stay in `workspace`, their count goes to *chunksOut, grad is not touched
+    int rc = weight_acts_check(images, hidActs, grad ? grad : (float*)workspace, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
                                numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
     if (rc) return rc;
     const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
@@ -563,6 +564,7 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
         }
         rc = MCN_LAUNCH_CHECK("convWeightActsReduced");
         if (rc) return rc;
+        if (chunksOut) { *chunksOut = pl.strips; return MCN_OK; }
         MCN_LAUNCH(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, s, (const float*)workspace, grad, pl.strips, cols, scaleTargets);
         return MCN_LAUNCH_CHECK("convWeightActsReduced");
     }
@@ -577,6 +579,7 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
                             numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
                             mpc, 0.f, scaleOutput, (hipStream_t)stream);
     if (rc) return rc;
+    if (chunksOut) { *chunksOut = chunks; return MCN_OK; }
     MCN_LAUNCH(k_reduce_chunks, dim3(divup(cols, 16)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, grad, chunks, cols, scaleTargets);
     return MCN_LAUNCH_CHECK("convWeightActsReduced");
@@ -590,6 +593,30 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
     return conv_weight_acts_reduced_impl(images, hidActs, grad, workspace, workspaceBytes, numImages, imgStride, imgSizeY, imgSizeX,
                                          numImgColors, numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride,
                                          numGroups, scaleTargets, scaleOutput, stream);
+}
+
+// number of slabs mcn_conv_weight_acts_partials produces for 16-byte aligned operands of this shape
+MCN_API int mcn_conv_weight_acts_partials_count(int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                                int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups) {
+    if (numImages <= 0 || numImgColors <= 0 || numFilters <= 0 || filterSize <= 0 || numModulesY <= 0 || numModulesX <= 0 || numGroups <= 0 ||
+        numImgColors % numGroups != 0)
+        return 0;
+    const int K = (numImgColors / numGroups) * filterSize * filterSize, M = numModulesY * numModulesX;
+    const StripPlan pl = strip_plan(numImgColors, numFilters, filterSize, numModulesY, numModulesX, moduleStride, numGroups);
+    const bool vecn = (numImages % 4 == 0) && (imgStride % 4 == 0);
+    const size_t imgBytes = (size_t)numImgColors * imgSizeY * imgSizeX * imgStride * 4, hidBytes = (size_t)numFilters * M * numImages * 4;
+    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31)) return pl.strips;
+    return divup(M, reduced_modules_per_chunk(M, K, numFilters));
+}
+
+MCN_API int mcn_conv_weight_acts_partials(const float* images, const float* hidActs, void* partials, size_t partialsBytes,
+                                          int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                          int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                          int numGroups, float scaleOutput, int* numChunks, void* stream) {
+    MCN_REQUIRE(partials && numChunks, "convWeightActsPartials: null pointer");
+    return conv_weight_acts_reduced_impl(images, hidActs, nullptr, partials, partialsBytes, numImages, imgStride, imgSizeY, imgSizeX,
+                                         numImgColors, numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride,
+                                         numGroups, 0.f, scaleOutput, stream, numChunks);
 }
 
 // ---------------------------------------------------------------------------------------------

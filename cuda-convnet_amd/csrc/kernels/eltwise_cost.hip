@@ -237,9 +237,20 @@ MCN_API size_t mcn_add_sum_multi_workspace_bytes(const mcn_row_sum_item* items, 
     for (int i = 0; i < count; i++) need += mcn_add_sum_workspace_bytes(items[i].rows, items[i].cols, 1);
     return need;
 }
+static int add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream, float* const* stage1Out);
 MCN_API int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream) {
+    return add_sum_multi(items, count, workspace, workspaceBytes, stream, nullptr);
+}
+// Only the first of the two launches: matrices with rows of at most 8192 columns are finished, every other matrix i leaves
+// its partial row sums -- (rows_i x chunks_i) floats, chunks_i = ceil(cols_i / 8192) -- in partialsOut[i] for a consumer
+// that finishes them itself (the fused update, mcn_sgd_plan_build_fused).
+MCN_API int mcn_add_sum_multi_stage1(const mcn_row_sum_item* items, int count, float* const* partialsOut, void* stream) {
+    MCN_REQUIRE(partialsOut, "addSumMultiStage1: null pointer");
+    return add_sum_multi(items, count, nullptr, 0, stream, partialsOut);
+}
+static int add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream, float* const* stage1Out) {
     MCN_REQUIRE(items && count > 0 && count <= ROWSUM_MAX_ITEMS, "addSumMulti: 1..%d matrices per call", ROWSUM_MAX_ITEMS);
-    const size_t need = mcn_add_sum_multi_workspace_bytes(items, count);
+    const size_t need = stage1Out ? 0 : mcn_add_sum_multi_workspace_bytes(items, count);
     if (need > 0 && (!workspace || workspaceBytes < need)) {
         mcn_set_error("addSumMulti: workspace %zu < %zu bytes", workspaceBytes, need);
         return MCN_EWORKSPACE;
@@ -262,6 +273,10 @@ MCN_API int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* wo
             blocks1 += it.rows;
         } else {
             const int chunks = divup(it.cols, ROWSUM_CHUNK);
+            if (stage1Out) {
+                MCN_REQUIRE(stage1Out[i], "addSumMultiStage1: matrix %d needs a partials buffer", i);
+                part = stage1Out[i];
+            }
             g.out = part; g.chunks = chunks; g.finalStage = 0; g.scaleThis = 0.f; g.scaleSum = 1.f;
             blocks1 += it.rows * chunks;
             RowSumSeg& h = s2.seg[s2.count++];
@@ -274,7 +289,7 @@ MCN_API int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* wo
     }
     hipStream_t s = (hipStream_t)stream;
     MCN_LAUNCH(k_row_sums_multi, dim3(blocks1), dim3(256), 0, s, s1);
-    if (s2.count > 0) MCN_LAUNCH(k_row_sums_multi, dim3(blocks2), dim3(256), 0, s, s2);
+    if (s2.count > 0 && !stage1Out) MCN_LAUNCH(k_row_sums_multi, dim3(blocks2), dim3(256), 0, s, s2);
     return MCN_LAUNCH_CHECK("addSumMulti");
 }
 
@@ -1247,9 +1262,26 @@ struct SgdRec {
     float mom, wcEps;
     int useGrad, useWc;
     unsigned blockStart, pad;
+    // The gradient may still be in pieces when the update starts (mcn_sgd_plan_build_fused): kind 1 = `chunks` slabs of n
+    // floats (the module-chunk partials of a conv weight gradient, mcn_conv_weight_acts_partials), kind 2 = n rows of
+    // `chunks` partial row sums (stage 1 of a bias gradient, mcn_add_sum_multi_stage1).  The blocks of such a record first
+    // finish the sum -- with the code and in the order of the stand-alone second stages (k_reduce_chunks / k_row_sum_short),
+    // so the values are bit-identical to theirs -- store it to grad and then update their elements.
+    const float* part;
+    int chunks, kind;
+    float partScale, pad2;
 };
+__device__ __forceinline__ void sgd_apply_one(const SgdRec& r, size_t e, float g) {
+    float v = r.inc[e];
+    const float w = r.W[e];
+    v = r.mom * v + 1.f * g;
+    if (r.useWc) v = 1.f * v + r.wcEps * w;
+    r.inc[e] = v;
+    r.W[e] = w + v;
+}
 __global__ __launch_bounds__(256) void k_sgd_planned(const SgdRec* __restrict__ plan, int count) {
     __shared__ int which;
+    __shared__ float sh[16][17];
     if (threadIdx.x == 0) {
         int t = 0;
         while (t + 1 < count && plan[t + 1].blockStart <= blockIdx.x) t++;
@@ -1257,6 +1289,52 @@ __global__ __launch_bounds__(256) void k_sgd_planned(const SgdRec* __restrict__ 
     }
     __syncthreads();
     const SgdRec r = plan[which];
+    if (r.kind == 1) {  // 16 columns of a (chunks x n) stack of partial gradients: as k_reduce_chunks (conv_bwd_weights.hip)
+        const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+        const size_t c = (size_t)(blockIdx.x - r.blockStart) * 16 + cl;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < r.n) {
+            for (int q = rg; q < r.chunks; q += 512) {
+                float v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) v[u] = q + 16 * u < r.chunks ? r.part[(size_t)(q + 16 * u) * r.n + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 32; u += 4) {
+                    s0 += v[u];
+                    s1 += v[u + 1];
+                    s2 += v[u + 2];
+                    s3 += v[u + 3];
+                }
+            }
+        }
+        sh[rg][cl] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        for (int o = 8; o > 0; o >>= 1) {
+            if (rg < o) sh[rg][cl] += sh[rg + o][cl];
+            __syncthreads();
+        }
+        if (rg == 0 && c < r.n) {
+            const float g = sh[0][cl];
+            const_cast<float*>(r.grad)[c] = g;
+            sgd_apply_one(r, c, g);
+        }
+        return;
+    }
+    if (r.kind == 2) {  // 4 rows of (n x chunks) partial row sums, one wave per row: as row_sum_short4
+        const size_t row = (size_t)(blockIdx.x - r.blockStart) * 4 + (threadIdx.x >> 6);
+        const int lane = threadIdx.x & 63;
+        if (row >= r.n) return;
+        const float* m = r.part + row * r.chunks;
+        float v = 0.f;
+        for (int c = lane; c < r.chunks; c += 64) v += m[c];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) {
+            const float g = 0.f + r.partScale * v;
+            const_cast<float*>(r.grad)[row] = g;
+            sgd_apply_one(r, row, g);
+        }
+        return;
+    }
     const size_t base = (size_t)(blockIdx.x - r.blockStart) * SGD_BLOCK_ELEMS;
 #pragma unroll
     for (int rep = 0; rep < SGD_BLOCK_ELEMS / 1024; rep++) {
@@ -1281,7 +1359,8 @@ __global__ __launch_bounds__(256) void k_sgd_planned(const SgdRec* __restrict__ 
     }
 }
 MCN_API size_t mcn_sgd_plan_bytes(int count) { return (size_t)(count > 0 ? count : 1) * sizeof(SgdRec); }
-MCN_API int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, size_t planBytes, int* numBlocksOut, void* stream) {
+static int sgd_plan_build(const mcn_sgd_item* items, const mcn_sgd_partials* parts, int count, void* devicePlan, size_t planBytes,
+                          int* numBlocksOut, void* stream) {
     MCN_REQUIRE(items && devicePlan && numBlocksOut && count > 0, "sgdPlanBuild: bad argument");
     MCN_REQUIRE(planBytes >= mcn_sgd_plan_bytes(count), "sgdPlanBuild: plan buffer too small");
     std::vector<SgdRec> recs(count);
@@ -1294,12 +1373,29 @@ MCN_API int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devic
         r.W = it.W; r.inc = it.inc; r.grad = it.grad; r.n = it.n;
         r.mom = it.mom; r.wcEps = -it.wc * it.eps; r.useGrad = it.useGrad; r.useWc = it.wc > 0 ? 1 : 0;
         r.blockStart = blocks; r.pad = 0;
-        blocks += (unsigned)divup_sz(it.n, SGD_BLOCK_ELEMS);
+        r.part = nullptr; r.chunks = 0; r.kind = 0; r.partScale = 1.f; r.pad2 = 0.f;
+        if (parts && parts[i].data) {
+            const mcn_sgd_partials& q = parts[i];
+            MCN_REQUIRE(it.useGrad && it.grad && q.count > 0 && (q.kind == 1 || (q.kind == 2 && q.count <= 256)),
+                        "sgdPlanBuildFused: item %d: bad partials (kind 1, or kind 2 with at most 256 partial sums per row)", i);
+            r.part = q.data; r.chunks = q.count; r.kind = q.kind; r.partScale = q.scale;
+            blocks += (unsigned)divup_sz(it.n, q.kind == 1 ? 16 : 4);
+        } else {
+            blocks += (unsigned)divup_sz(it.n, SGD_BLOCK_ELEMS);
+        }
     }
     *numBlocksOut = (int)blocks;
     int rc = mcn_check_hip(hipMemcpyAsync(devicePlan, recs.data(), recs.size() * sizeof(SgdRec), hipMemcpyHostToDevice, (hipStream_t)stream), "sgdPlanBuild upload");
     if (rc) return rc;
     return mcn_check_hip(hipStreamSynchronize((hipStream_t)stream), "sgdPlanBuild sync");  // recs goes out of scope
+}
+MCN_API int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, size_t planBytes, int* numBlocksOut, void* stream) {
+    return sgd_plan_build(items, nullptr, count, devicePlan, planBytes, numBlocksOut, stream);
+}
+MCN_API int mcn_sgd_plan_build_fused(const mcn_sgd_item* items, const mcn_sgd_partials* partials, int count, void* devicePlan,
+                                     size_t planBytes, int* numBlocksOut, void* stream) {
+    MCN_REQUIRE(partials, "sgdPlanBuildFused: null pointer");
+    return sgd_plan_build(items, partials, count, devicePlan, planBytes, numBlocksOut, stream);
 }
 MCN_API int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream) {
     MCN_REQUIRE(devicePlan && count > 0 && numBlocks > 0, "sgdUpdatePlanned: bad argument");

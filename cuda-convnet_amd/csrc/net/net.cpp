@@ -343,7 +343,7 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
             if (_net->biasBatching()) {  // a row sum like every other layer's: all of them in one launch at the end of the pass
                 int rows, cols;
                 biasSumShape(_net->numCases(), rows, cols);
-                _net->queueBiasSum(_biases->gradBuf(), v, rows, cols, gradScale(_biases->eps(), pt));
+                _net->queueBiasSum(_biases->gradBuf(), v, rows, cols, gradScale(_biases->eps(), pt), _biasParts.p);
             } else {
                 ProfScope ps(_net, _name, "bpropBiases");
                 bpropBiases(v, pt);
@@ -388,6 +388,24 @@ void WeightLayer::copyToCPU() {
 void WeightLayer::copyToGPU() {
     for (auto& w : _weights) w->copyToGPU(_net->stream());
     _biases->copyToGPU(_net->stream());
+}
+bool WeightLayer::planFusedTail(int numCases) {
+    // bias gradient = row sums of the layer's gradient matrix; rows longer than one chunk (conv layers with shared biases)
+    // take two stages, and the second one can ride in the update
+    _biases->partials = Weights::Partials();
+    if (!(_biases->eps() > 0)) return true;
+    int rows, cols;
+    biasSumShape(numCases, rows, cols);
+    const size_t bytes = mcn_add_sum_workspace_bytes(rows, cols, 1);
+    if (bytes == 0) return true;
+    const int chunks = (int)(bytes / sizeof(float) / rows);
+    if (chunks > 256) return false;  // (rows of more than 2 M columns: their second stage is a block reduction, not a wave's)
+    _biasParts.ensure(bytes / sizeof(float));
+    _biases->partials.data = _biasParts.p;
+    _biases->partials.count = chunks;
+    _biases->partials.kind = 2;
+    _biases->partials.scale = _biases->eps() / (float)(numCases * _net->worldSize());
+    return true;
 }
 void WeightLayer::collectWeights(std::vector<Weights*>& out) {
     for (auto& w : _weights) out.push_back(w.get());
@@ -619,6 +637,27 @@ size_t LocalLayer::workspaceBytes(int maxCases) {
     return b;
 }
 
+bool LocalLayer::planFusedTail(int numCases) {
+    if (!WeightLayer::planFusedTail(numCases)) return false;
+    _wgradParts.resize(_weights.size());
+    _wgradChunks.assign(_weights.size(), 0);
+    for (size_t i = 0; i < _weights.size(); i++) {
+        Weights& w = *_weights[i];
+        w.partials = Weights::Partials();
+        if (!_conv || !w.owner() || !(w.eps() > 0)) continue;
+        const int channels = sparse((int)i) ? wideChannels((int)i) : (int)_channels[i];
+        const size_t bytes = mcn_conv_weight_acts_reduced_workspace_bytes(channels, _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_groups[i]);
+        if (!_wgradParts[i]) _wgradParts[i].reset(new DBuf());
+        _wgradParts[i]->ensure(bytes / sizeof(float) + 4);
+        w.partials.data = _wgradParts[i]->p;
+        w.partials.kind = 1;
+        w.partials.count = mcn_conv_weight_acts_partials_count(numCases, numCases, (int)_imgSizeY[i], (int)_imgSizeX[i], channels, _filters,
+                                                               (int)_filterSize[i], _modulesY, _modulesX, (int)_stride[i], (int)_groups[i]);
+        if (w.partials.count <= 0) w.partials = Weights::Partials();
+    }
+    return true;
+}
+
 void LocalLayer::allocate(int maxCases) {
     WeightLayer::allocate(maxCases);
     for (size_t i = 0; i < _sparse.size(); i++)
@@ -719,6 +758,15 @@ void LocalLayer::bpropWeights(float* v, int i, PassType pt) {
     // random-sparse input: the re-ordered tensor forward left behind, as numGroups*filterChannels dense grouped channels
     const float* in = sparse(i) ? _sparse[i]->gathered.p : _prev[i]->getActs();
     const int channels = sparse(i) ? wideChannels(i) : (int)_channels[i];
+    if (_conv && pt == PASS_TRAIN && _net->fusedTailNow() && w.partials.kind == 1 && w.partials.count > 0) {
+        // first stage only: the update launch sums the module-chunk partials itself (ConvNet::fusedTailNow)
+        int chunks = 0;
+        chk(mcn_conv_weight_acts_partials(in, v, _wgradParts[i]->p, _wgradParts[i]->cap * sizeof(float), n, n, (int)_imgSizeY[i],
+                                          (int)_imgSizeX[i], channels, _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
+                                          (int)_stride[i], (int)_groups[i], gradScale(w.eps(), pt), &chunks, _net->stream()), "convWeightActs (partials)");
+        if (chunks != w.partials.count) throw NetError("layer '" + _name + "': the weight gradient came in another number of pieces than planned");
+        return;
+    }
     if (_conv) {
         // layer.cu:476-496: weightActs into a (modules/partialSum) x weights temporary, then addSum over
         // its rows.  Here: one call with a private module split + fixed-order reduction; the value is
@@ -1680,6 +1728,7 @@ void ConvNet::resetAfterError() {
     _gradPending = false;
     _exchangeWorkPending = false;
     _earlyUpdateIssued = false;
+    _fusedTailNow = false;
     _passNow.clear();
     _wlSeen = 0;
     _biasBatch[0].clear();
@@ -1805,6 +1854,39 @@ void ConvNet::allocate(int maxCases) {
         const size_t pb = mcn_sgd_plan_bytes(_sgdCount);
         _sgdPlan.ensure((pb + 3) / 4);
         chk(mcn_sgd_plan_build(items.data(), _sgdCount, _sgdPlan.p, pb, &_sgdBlocks, _stream), "sgd plan");
+    }
+    // ... and the same plan with the latency-only tail launches of a step folded in (fusedTailNow)
+    _fusedTailOk = false;
+    static const bool noFusedTail = getenv("MCN_NO_FUSED_TAIL") != nullptr || getenv("MCN_EARLY_SGD") != nullptr;
+    if (!dp && _fusion && !_hasSharing && !noFusedTail && biasBatching() && _sgdCount > 0) {
+        std::vector<::mcn_sgd_item> fi;
+        std::vector<::mcn_sgd_partials> fp;
+        bool any = false, expressible = true;
+        for (auto& l : _layers) expressible = l->planFusedTail(maxCases) && expressible;
+        for (auto& l : _layers) {
+            std::vector<Weights*> ws_;
+            l->collectWeights(ws_);
+            for (Weights* w : ws_) {
+                ::mcn_sgd_item it;
+                if (!w->planItem(dp, it)) continue;
+                ::mcn_sgd_partials q = {nullptr, 0, 0, 1.f};
+                if (w->partials.data && it.useGrad) {
+                    q.data = w->partials.data; q.count = w->partials.count; q.kind = w->partials.kind; q.scale = w->partials.scale;
+                    any = true;
+                } else {
+                    w->partials = Weights::Partials();
+                }
+                fi.push_back(it);
+                fp.push_back(q);
+            }
+        }
+        if (any && expressible && (int)fi.size() == _sgdCount) {
+            const size_t pb = mcn_sgd_plan_bytes(_sgdCount);
+            _sgdFused.ensure((pb + 3) / 4);
+            chk(mcn_sgd_plan_build_fused(fi.data(), fp.data(), _sgdCount, _sgdFused.p, pb, &_sgdFusedBlocks, _stream), "sgd plan (fused tail)");
+            _sgdFusedCount = _sgdCount;
+            _fusedTailOk = true;
+        }
     }
     int nc = 0;
     for (CostLayer* c : _costs) nc += c->numCostValues();
@@ -1946,8 +2028,8 @@ bool ConvNet::biasBatching() const {
     static const bool off = getenv("MCN_NO_BIAS_BATCH") != nullptr;
     return !off && _fusion;
 }
-void ConvNet::queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum) {
-    _biasBatch[t_stream == 1 ? 1 : 0].push_back({tgt, mat, rows, cols, scaleSum});
+void ConvNet::queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum, float* partsOut) {
+    _biasBatch[t_stream == 1 ? 1 : 0].push_back({tgt, mat, rows, cols, scaleSum, partsOut});
 }
 void ConvNet::flushBiasSums(int which) {
     std::vector<BiasSum>& b = _biasBatch[which >= 0 ? which : (t_stream == 1 ? 1 : 0)];
@@ -1961,7 +2043,11 @@ void ConvNet::flushBiasSums(int which) {
             items[k].tgt = q.tgt; items[k].mat = q.mat; items[k].rows = q.rows; items[k].cols = q.cols;
             items[k].scaleThis = 0.f; items[k].scaleSum = q.scaleSum;
         }
-        if (mcn_add_sum_multi_workspace_bytes(items, cnt) <= workspaceBytes()) {
+        if (_fusedTailNow) {  // the long rows' second stage happens in the update launch (their partial sums stay in the layers' buffers)
+            float* parts[8];
+            for (int k = 0; k < cnt; k++) parts[k] = b[i + k].partsOut;
+            chk(mcn_add_sum_multi_stage1(items, cnt, parts, stream()), "bias gradients (stage 1)");
+        } else if (mcn_add_sum_multi_workspace_bytes(items, cnt) <= workspaceBytes()) {
             chk(mcn_add_sum_multi(items, cnt, workspace(), workspaceBytes(), stream()), "bias gradients");
         } else {
             for (int k = 0; k < cnt; k++)
@@ -2296,6 +2382,8 @@ void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
         std::lock_guard<std::mutex> lk(_failMutex);
         _failArmed = !_failAt.empty();
     }
+    // the fused tail is planned for full minibatches (the bias scale eps / numCases is part of the plan)
+    _fusedTailNow = _fusedTailOk && pt == PASS_TRAIN && _numCases == _allocatedCases && !_profiling;
     if (_phases) profBegin("phase.backward_data_chain");
     for (CostLayer* c : _costs) c->bprop(pt);
     if (_phases) {
@@ -2324,9 +2412,12 @@ void ConvNet::updateWeights() {  // convnet.cu:190-194
         if (_earlyUpdateIssued) {  // this pass has updated everything but its last weight layer already
             _earlyUpdateIssued = false;
             if (_sgdLateCount > 0) chk(mcn_sgd_update_planned(_sgdLate.p, _sgdLateCount, _sgdLateBlocks, _stream), "sgd update (late)");
+        } else if (_fusedTailNow) {
+            chk(mcn_sgd_update_planned(_sgdFused.p, _sgdFusedCount, _sgdFusedBlocks, _stream), "sgd update (fused tail)");
         } else {
             chk(mcn_sgd_update_planned(_sgdPlan.p, _sgdCount, _sgdBlocks, _stream), "sgd update");
         }
+        _fusedTailNow = false;
         for (auto& l : _layers) l->weightsUpdated();
     } else {
         for (auto& l : _layers) l->updateWeights();

@@ -71,6 +71,10 @@ class Weights {
     float* gradBuf() { return _src ? _src->_grad : _grad; }
     float* getGrad(bool dp) { return (_useGrad || dp) ? gradBuf() : inc(); }  // weights.cuh:103-106
     void setGradBuf(float* g) { _grad = g; }
+    // the fused update (ConvNet::fusedTail): this matrix's gradient arrives as `count` partial pieces the update itself sums
+    // (kind 1: module-chunk slabs of a conv weight gradient; kind 2: stage-1 row sums of a bias gradient, scaled by `scale`)
+    struct Partials { const float* data = nullptr; int count = 0, kind = 0; float scale = 1.f; };
+    Partials partials;
     bool owner() const { return _src == nullptr; }
     bool useGrad() const { return _useGrad; }
     float eps() const { return _eps; }
@@ -134,6 +138,7 @@ class Layer {
     virtual void copyToGPU() {}
     virtual void checkGradients(std::vector<struct GradCheckResult>& out, long maxElems, bool central) {}
     virtual void collectWeights(std::vector<Weights*>& out) {}
+    virtual bool planFusedTail(int numCases) { return true; }  // fill Weights::partials for a pass of numCases columns; false: not expressible
 
     const std::string& name() const { return _name; }
     const std::string& type() const { return _type; }
@@ -196,6 +201,7 @@ class WeightLayer : public Layer {
     void copyToGPU() override;
     void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) override;
     void collectWeights(std::vector<Weights*>& out) override;
+    bool planFusedTail(int numCases) override;
     Weights& weights(int i) { return *_weights[i]; }
     int numWeights() const { return (int)_weights.size(); }
     NeuronLayer* fusedNeuron = nullptr;
@@ -208,6 +214,7 @@ class WeightLayer : public Layer {
     float gradScale(float eps, PassType pt) const;  // eps / (numCases * worldSize), 1 for PASS_GC
     std::vector<std::unique_ptr<Weights>> _weights;
     std::unique_ptr<Weights> _biases;
+    DBuf _biasParts;  // stage-1 row sums of the bias gradient (fused update)
     float _wStep = 0.001f, _bStep = 0.002f;  // layer.cu:294-295
 };
 
@@ -235,7 +242,10 @@ class LocalLayer : public WeightLayer {
    public:
     LocalLayer(ConvNet* net, const Params& p, bool useGrad, bool conv);
     size_t workspaceBytes(int maxCases) override;
+    bool planFusedTail(int numCases) override;
    protected:
+    std::vector<std::unique_ptr<DBuf>> _wgradParts;  // conv: module-chunk partials of each weight gradient (fused update)
+    std::vector<int> _wgradChunks;
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;
     void bpropBiases(float* v, PassType) override;
@@ -714,7 +724,11 @@ class ConvNet {
     bool lastWeightLayerOfPass(WeightLayer* wl);
     // bias gradients of a backward pass, handed to ONE mcn_add_sum_multi by the last weight layer's bias piece (single GPU)
     bool biasBatching() const;
-    void queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum);
+    void queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum, float* partsOut);
+    // The tail of a single-GPU training step without its latency-only launches: the module-chunk reductions of the conv
+    // weight gradients and the second stage of the long bias row sums happen inside the one update launch
+    // (mcn_sgd_plan_build_fused); bit-identical to the separate launches.  fusedTailNow: this pass takes that path.
+    bool fusedTailNow() const { return _fusedTailNow; }
     void flushBiasSums(int which = -1);  // -1: the calling thread's batch
     void failNextBackwardAt(const std::string& layer) { std::lock_guard<std::mutex> lk(_failMutex); _failAt = layer; }  // (any thread)
     bool _failArmed = false;
@@ -858,7 +872,10 @@ class ConvNet {
 
     // per-operation event timing (off on the normal path)
     bool _profiling = false, _phases = false;
-    struct BiasSum { float* tgt; const float* mat; int rows, cols; float scaleSum; };
+    struct BiasSum { float* tgt; const float* mat; int rows, cols; float scaleSum; float* partsOut; };
+    DBuf _sgdFused;
+    int _sgdFusedCount = 0, _sgdFusedBlocks = 0;
+    bool _fusedTailOk = false, _fusedTailNow = false;
     std::vector<BiasSum> _biasBatch[2];  // queued by closures on the main [0] / side [1] submitting thread
     std::string _failAt;   // failNextBackwardAt
     std::mutex _failMutex;

@@ -194,6 +194,17 @@ int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, floa
                                  int paddingStart, int moduleStride, int numGroups,
                                  float scaleTargets, float scaleOutput, void* stream);
 
+/* First stage only of mcn_conv_weight_acts_reduced (the reference's own first stage: convWeightActs into its partialSum
+ * temporary, layer.cu:476-485): `partials` receives *numChunks slabs of (filterChannels*fs*fs x numFilters) floats, each
+ * scaled by scaleOutput, whose sum over the slabs is the weight gradient; partialsBytes >=
+ * mcn_conv_weight_acts_reduced_workspace_bytes(...).  For a consumer that sums them itself (mcn_sgd_plan_build_fused).
+ * *numChunks depends only on the layer geometry and on whether numImages is a multiple of 32 (and 16-byte alignment). */
+int mcn_conv_weight_acts_partials_count(int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                        int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups);
+int mcn_conv_weight_acts_partials(const float* images, const float* hidActs, void* partials, size_t partialsBytes,
+                                  int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                  int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                  int numGroups, float scaleOutput, int* numChunks, void* stream);
 /* No counterpart in the reference.  mcn_conv_weight_acts_reduced for callers that cannot allocate device memory or
  * bring a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
  * module-chunk partials live in a static device array of mcn_conv_weight_acts_reduced_static_max_bytes() = 4 MiB
@@ -375,6 +386,10 @@ typedef struct mcn_row_sum_item {
 } mcn_row_sum_item;
 size_t mcn_add_sum_multi_workspace_bytes(const mcn_row_sum_item* items, int count);
 int mcn_add_sum_multi(const mcn_row_sum_item* items, int count, void* workspace, size_t workspaceBytes, void* stream);
+/* Only the first of the two launches: matrices whose rows have at most 8192 columns are finished; every other matrix i
+ * leaves (rows_i x ceil(cols_i / 8192)) partial row sums in partialsOut[i] (mcn_add_sum_workspace_bytes(rows_i, cols_i, 1)
+ * bytes), for mcn_sgd_plan_build_fused to finish inside the update. */
+int mcn_add_sum_multi_stage1(const mcn_row_sum_item* items, int count, float* const* partialsOut, void* stream);
 /* NVMatrix::add (nvmatrix.cuh eltwise WeightedAdd): a = sa*a + sb*b */
 int mcn_axpby(float* a, const float* b, size_t n, float sa, float sb, void* stream);
 /* NVMatrix::scale / copy with scale: out = s*in */
@@ -513,6 +528,19 @@ typedef struct mcn_sgd_item {
 size_t mcn_sgd_plan_bytes(int count);
 int mcn_sgd_plan_build(const mcn_sgd_item* items, int count, void* devicePlan, size_t planBytes, int* numBlocksOut, void* stream);
 int mcn_sgd_update_planned(const void* devicePlan, int count, int numBlocks, void* stream);
+/* A plan whose update also FINISHES gradients that are still in pieces when it starts (no counterpart in the reference,
+ * which runs addSum over its partialSum temporary as a launch of its own, layer.cu:486-495): partials[i].data == NULL
+ * for an ordinary item; kind 1: `count` slabs of items[i].n floats whose sum is the gradient (the module-chunk partials of
+ * mcn_conv_weight_acts_partials); kind 2: items[i].n rows of `count` partial row sums, gradient = scale * row sum (stage 1
+ * of mcn_add_sum_multi_stage1).  The sums use the code and order of the stand-alone second stages, so the updated weights
+ * are bit-identical to reduce-then-update; the finished gradient is also stored to items[i].grad. */
+typedef struct mcn_sgd_partials {
+    const float* data;
+    int count, kind;
+    float scale;
+} mcn_sgd_partials;
+int mcn_sgd_plan_build_fused(const mcn_sgd_item* items, const mcn_sgd_partials* partials, int count, void* devicePlan,
+                             size_t planBytes, int* numBlocksOut, void* stream);
 
 /* ---- data-parallel exchange (no counterpart in the reference, which is single-GPU: convnet.py:52-53).
  * RCCL is loaded lazily; one communicator per process (one process per GPU).

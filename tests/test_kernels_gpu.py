@@ -1013,3 +1013,70 @@ def test_fc_bprop_weights_all_inputs_in_one_launch(O_, Is, N):
     call('mcn_fc_bprop_weights_multi', d_dy, xa, ta_, ka, (C.c_float * len(Is))(*alphas), (C.c_float * len(Is))(*betas), len(Is), O_, N, None)
     for i in range(len(Is)):
         close(dT[i].numpy(), wants[i], what='dW[%d]' % i)
+
+
+@pytest.mark.parametrize('name', ['conv1_55', 'conv2', 'conv2_plus', 'conv1_39x31', 'cifar_conv1'])
+def test_fused_update_finishes_partial_gradients_bitwise(name):
+    """mcn_sgd_plan_build_fused: the update launch sums the module-chunk partials of a conv weight gradient
+    (mcn_conv_weight_acts_partials) and the stage-1 row sums of its bias gradient (mcn_add_sum_multi_stage1) itself.  Weights,
+    increments AND the stored gradients must equal, bit for bit, the chain of separate launches it replaces
+    (mcn_conv_weight_acts_reduced -> mcn_add_sum -> mcn_sgd_update_planned): same summation code, same order."""
+    class Item(C.Structure):
+        _fields_ = [('W', C.c_void_p), ('inc', C.c_void_p), ('grad', C.c_void_p), ('n', C.c_size_t),
+                    ('mom', C.c_float), ('wc', C.c_float), ('eps', C.c_float), ('useGrad', C.c_int)]
+
+    class Parts(C.Structure):
+        _fields_ = [('data', C.c_void_p), ('count', C.c_int), ('kind', C.c_int), ('scale', C.c_float)]
+
+    class RItem(C.Structure):
+        _fields_ = [('tgt', C.c_void_p), ('mat', C.c_void_p), ('rows', C.c_int), ('cols', C.c_int), ('scaleThis', C.c_float),
+                    ('scaleSum', C.c_float)]
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(77)
+    img, hid = dev(mk(rng, C_ * imgY * imgX, N)), dev(mk(rng, F * mY * mX, N))
+    K = (C_ // groups) * fs * fs
+    nW = K * F
+    W0, inc0 = mk(rng, nW), mk(rng, nW, scale=0.01)
+    b0, binc0 = mk(rng, F), mk(rng, F, scale=0.01)
+    other0 = mk(rng, 5000)  # an ordinary matrix in the same plan
+    L = capi.lib()
+    nbytes = ws_bytes('mcn_conv_weight_acts_reduced_workspace_bytes', C_, F, fs, mY, mX, groups)
+    rows, cols = F, mY * mX * N
+    bias_bytes = ws_bytes('mcn_add_sum_workspace_bytes', rows, cols, 1)
+    assert bias_bytes > 0, 'shape must take the two-stage row sum'
+    out = []
+    for fused in (False, True):
+        dW, dInc, dG = dev(W0), dev(inc0), dev_empty(nW, 0)
+        dB, dBinc, dBg = dev(b0), dev(binc0), dev_empty(F, 0)
+        dO, dOinc, dOg = dev(other0), dev(other0 * 0.01), dev(other0 * 0.001)
+        items = (Item * 3)(Item(dW.ptr, dInc.ptr, dG.ptr, nW, 0.9, 5e-4, 5e-4, 1), Item(dB.ptr, dBinc.ptr, dBg.ptr, F, 0.9, 0.0, 1e-3, 1),
+                           Item(dO.ptr, dOinc.ptr, dOg.ptr, 5000, 0.9, 5e-4, 5e-4, 1))
+        plan = capi.workspace(ws_bytes('mcn_sgd_plan_bytes', 3))
+        nb = C.c_int(0)
+        wsb = capi.workspace(nbytes)
+        bws = capi.workspace(bias_bytes)
+        ritems = (RItem * 1)(RItem(dBg.ptr, hid.ptr, rows, cols, 0.0, 1e-3 / N))
+        if not fused:
+            L.call('mcn_sgd_plan_build', C.cast(items, C.c_void_p), 3, plan, plan.nbytes, C.byref(nb), None)
+            for _ in range(2):
+                call('mcn_conv_weight_acts_reduced', img, hid, dG, wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 0.0, 5e-4 / N, None)
+                L.call('mcn_add_sum_multi', C.cast(ritems, C.c_void_p), 1, bws, bias_bytes, None)
+                L.call('mcn_sgd_update_planned', plan, 3, nb.value, None)
+        else:
+            chunks = L.raw('mcn_conv_weight_acts_partials_count')(N, N, imgY, imgX, C_, F, fs, mY, mX, stride, groups)
+            assert chunks > 0
+            parts = (Parts * 3)(Parts(wsb.ptr, chunks, 1, 1.0), Parts(bws.ptr, bias_bytes // 4 // rows, 2, 1e-3 / N), Parts(None, 0, 0, 1.0))
+            L.call('mcn_sgd_plan_build_fused', C.cast(items, C.c_void_p), C.cast(parts, C.c_void_p), 3, plan, plan.nbytes, C.byref(nb), None)
+            for _ in range(2):
+                got = C.c_int(0)
+                call('mcn_conv_weight_acts_partials', img, hid, wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 5e-4 / N, C.byref(got), None)
+                assert got.value == chunks
+                pout = (C.c_void_p * 1)(bws.ptr)
+                L.call('mcn_add_sum_multi_stage1', C.cast(ritems, C.c_void_p), 1, pout, None)
+                L.call('mcn_sgd_update_planned', plan, 3, nb.value, None)
+        out.append([x.numpy().copy() for x in (dW, dInc, dG, dB, dBinc, dBg, dO, dOinc)])
+    for a, b, what in zip(out[0], out[1], ('W', 'inc', 'grad', 'bias', 'biasInc', 'biasGrad', 'other', 'otherInc')):
+        assert np.array_equal(a, b), '%s: %s differs between the fused and the separate tail' % (name, what)
+    assert np.abs(out[0][2]).max() > 0 and np.abs(out[0][5]).max() > 0

@@ -156,3 +156,22 @@ def test_step_graph_replay_equals_eager_bitwise(name):
                 assert np.array_equal(a, b), '%s %s[%d] differs between graph replay and eager submission' % (la['name'], key, i)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), '%s %s differs between graph replay and eager submission' % (la['name'], key)
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_fused_update_tail_equals_separate_launches_bitwise(name):
+    """The single-GPU step finishes the conv weight gradients' module-chunk sums and the second stage of the long bias row
+    sums inside the update launch (ConvNet::fusedTailNow; MCN_NO_FUSED_TAIL=1 keeps the separate launches).  Same code,
+    same order of additions: identical weights after three steps, including a ragged last minibatch that takes the
+    separate path in both runs."""
+    La, ca = train3(name, {})
+    Lb, cb = train3(name, {'MCN_NO_FUSED_TAIL': '1'})
+    assert ca == cb, (ca, cb)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between the fused and the separate tail' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between the fused and the separate tail' % (la['name'], key)
