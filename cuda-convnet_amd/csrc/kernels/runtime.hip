@@ -238,6 +238,70 @@ MCN_API int mcn_stream_tick(int* flag, int value, void* stream) {
 }
 
 // ---------------------------------------------------------------------------
+// Stream gates: cross-stream ordering by a spinning one-thread kernel instead of a barrier packet (mi_convnet.h).
+// ---------------------------------------------------------------------------
+__global__ void k_stream_signal(int* gate, int value) {
+    __hip_atomic_store(gate, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void k_stream_gate(int* gate, int value, long long timeoutTicks) {
+    const long long t0 = wall_clock64();  // 100 MHz constant clock
+    for (;;) {
+        const int v = __hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - value) >= 0) return;
+        if (wall_clock64() - t0 > timeoutTicks) {  // the producer never came: end anyway, say so
+            __hip_atomic_store(gate + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+MCN_API int mcn_gate_alloc(int** gate) {
+    MCN_REQUIRE(gate, "gateAlloc: null pointer");
+    int rc = mcn_check_hip(hipMalloc((void**)gate, 64), "hipMalloc (gate)");
+    if (rc) return rc;
+    return mcn_check_hip(hipMemset(*gate, 0, 64), "hipMemset (gate)");
+}
+MCN_API int mcn_gate_free(int* gate) { return gate ? mcn_check_hip(hipFree(gate), "hipFree (gate)") : MCN_OK; }
+MCN_API int mcn_stream_signal(int* gate, int value, void* stream) {
+    MCN_REQUIRE(gate, "streamSignal: null pointer");
+    MCN_LAUNCH(k_stream_signal, dim3(1), dim3(1), 0, (hipStream_t)stream, gate, value);
+    return mcn_check_hip(hipGetLastError(), "streamSignal");
+}
+MCN_API int mcn_stream_gate(int* gate, int value, int timeoutMs, void* stream) {
+    MCN_REQUIRE(gate && timeoutMs > 0, "streamGate: bad argument");
+    tick_send_now(3);  // (an armed tick of this thread first: whoever polls for it may be the one that signals this gate)
+    MCN_LAUNCH(k_stream_gate, dim3(1), dim3(1), 0, (hipStream_t)stream, gate, value, (long long)timeoutMs * 100000ll);
+    return mcn_check_hip(hipGetLastError(), "streamGate");
+}
+MCN_API int mcn_gate_timed_out(int* gate, int* timedOut, void* stream) {
+    MCN_REQUIRE(gate && timedOut, "gateTimedOut: null pointer");
+    int rc = mcn_check_hip(hipMemcpyAsync(timedOut, gate + 1, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream), "hipMemcpyAsync (gate)");
+    if (rc) return rc;
+    return mcn_check_hip(hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize (gate)");
+}
+MCN_API int mcn_gate_selftest(int* gate, void* waiter, void* signaller, int* concurrent) {
+    MCN_REQUIRE(gate && concurrent && waiter != signaller, "gateSelftest: bad argument");
+    *concurrent = 0;
+    int rc = mcn_check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (rc) return rc;
+    rc = mcn_check_hip(hipMemset(gate, 0, 64), "hipMemset (gate)");
+    if (rc) return rc;
+    // the gate first, its signal only once the gate is certainly spinning: streams that share a hardware queue never
+    // reach the signal, the gate runs into its (short) timeout and says so
+    MCN_LAUNCH(k_stream_gate, dim3(1), dim3(1), 0, (hipStream_t)waiter, gate, 1, 20ll * 100000ll);
+    const uint64_t t0 = mcn_now_ns();
+    while (mcn_now_ns() - t0 < 2000000ull) {}
+    MCN_LAUNCH(k_stream_signal, dim3(1), dim3(1), 0, (hipStream_t)signaller, gate, 1);
+    rc = mcn_check_hip(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    if (rc) return rc;
+    int h[2] = {0, 0};
+    rc = mcn_check_hip(hipMemcpy(h, gate, sizeof(h), hipMemcpyDeviceToHost), "hipMemcpy (gate)");
+    if (rc) return rc;
+    *concurrent = (h[0] == 1 && h[1] == 0) ? 1 : 0;
+    return mcn_check_hip(hipMemset(gate, 0, 64), "hipMemset (gate)");
+}
+
+// ---------------------------------------------------------------------------
 // RCCL, loaded on first use so that single-GPU users never pay for it.
 // Only the entry points below are bound (signatures from rccl.h).
 // ---------------------------------------------------------------------------

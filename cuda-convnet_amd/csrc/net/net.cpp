@@ -1193,7 +1193,11 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
         _prev[1]->rcvdB() == 0)
         early = _prev[1]->getActsGrad();
     const float coeff = _coeff;
-    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather, early, coeff] {
+    // (the seeded form hands _evReady to the layer below, and in a data-parallel run the side thread waits for the exchange
+    // stream inside this closure: both keep the event)
+    const int gateSeq = (!early && !gather && _net->gatesUsable()) ? _net->nextGateSeq() : 0;
+    _readyGateSeq = gateSeq;
+    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather, early, coeff, gateSeq] {
         if (gather) {
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
             _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
@@ -1202,7 +1206,8 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
         chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, gather ? nullptr : _pairStats.p, dCost, gather ? _gathered.p : nullptr,
                           gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
         if (early) chk(mcn_l2sn_grad_from_stats(data, early, D, n, _pairStats.p, _info.p, 0, coeff, _net->stream()), "l2sn grad (early)");
-        chk(timedEventRecord(_evReady, _net->stream()), "event record");
+        if (gateSeq) _net->signalGate(gateSeq);
+        else chk(timedEventRecord(_evReady, _net->stream()), "event record");
     });
     _earlyGrad = early != nullptr;
     if (early) _prev[1]->seedGrad(_evReady, _readyTicket);
@@ -1219,9 +1224,15 @@ void L2SNCostLayer::bprop(PassType pt) {
 
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
-    if (_readyOnExchange) _net->waitExchangeSubmitted(_readyTicket);  // that thread has recorded _evReady
-    else _net->waitSideSubmitted(_readyTicket);
-    chk(timedStreamWait(_net->stream(), _evReady), "wait event");
+    if (_readyGateSeq && t_stream == 0) {
+        // a gate may be queued before its signal has been launched: no hand-shake with the side thread, no barrier packet
+        _net->awaitGate(_readyGateSeq);
+        _readyGateSeq = 0;
+    } else {
+        if (_readyOnExchange) _net->waitExchangeSubmitted(_readyTicket);  // that thread has recorded _evReady
+        else _net->waitSideSubmitted(_readyTicket);
+        chk(timedStreamWait(_net->stream(), _evReady), "wait event");
+    }
     if (_readyOnExchange) _net->exchangeWorkJoined();  // the main stream now follows everything that task issued
     chk(mcn_l2sn_grad_from_stats(_prev[1]->getActs(), _prev[1]->getActsGrad(), _prev[1]->outputs(), _net->numCases(), _pairStats.p,
                                  _info.p, scaleTargets == 1 ? 1 : 0, _coeff, _net->stream()), "l2sn grad");
@@ -1594,6 +1605,7 @@ ConvNet::~ConvNet() {
     for (void* e : _bucketEvents) mcn_event_destroy(e);
     if (_gradStream) mcn_stream_destroy(_gradStream);
     for (void* e : _forkEvents) mcn_event_destroy(e);
+    if (_gate) mcn_gate_free(_gate);
     if (_tickFlag) mcn_tick_free(_tickFlag);
     if (_tickFlagSide) mcn_tick_free(_tickFlagSide);
     if (_evJoin) mcn_event_destroy(_evJoin);
@@ -1722,6 +1734,9 @@ void ConvNet::resetAfterError() {
     };
     drain(_side);
     drain(_commSub);
+    // a gate the failed pass queued on the main stream may wait for a signal that will never be sent (the closure that
+    // carried it was dropped): release it from the side stream, which is idle now
+    if (_gate && _gateOk) mcn_stream_signal(_gate, _gateSeq, _gradStream);
     _deferred.clear();
     _deferredUnits = 0;
     _late.clear();
@@ -1761,6 +1776,10 @@ void ConvNet::resetAfterError() {
             if (sm->costState.p) mcn_memset(sm->costState.p, 0, sm->costStateBytes, _stream);
     if (_dpOn) _failed = true;
     mcn_device_sync();  // (a sticky device error shows up in the next call's status)
+    if (_gate && _gateOk) {  // a gate that did run into its timeout has been reported with this error: start clean
+        mcn_memset(_gate + 1, 0, sizeof(int), _stream);
+        mcn_stream_sync(_stream);
+    }
 }
 
 void ConvNet::initDevice() {  // convnet.cu:139-145
@@ -1784,6 +1803,13 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
             _commTicks = getenv("MCN_COMM_TICKS") != nullptr;
         }
         _side.start(_deviceID);
+        if (getenv("MCN_NO_GATES") == nullptr) {
+            chk(mcn_gate_alloc(&_gate), "gate");
+            int ok = 0;
+            chk(mcn_gate_selftest(_gate, _stream, _gradStream, &ok), "gate self-test");
+            _gateOk = ok != 0;  // (two streams on one hardware queue: a gate would only ever time out -- events then)
+            if (getenv("MCN_DEBUG_TIMES")) fprintf(stderr, "[mcn] stream gates: %s\n", _gateOk ? "on" : "off (streams share a hardware queue)");
+        }
     }
     // this thread's backward-data products share the GPU with the side stream's weight gradients: the form that leaves
     // them wave slots (mcn_set_thread_option, measured on the DeepID2+ step: 0.817 vs 0.905 ms).  The same form with one
@@ -1939,9 +1965,22 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
 void ConvNet::sync() {
     joinGradWork();
     chk(mcn_stream_sync(_stream), "sync");
+    if (_gate && _gateOk) {
+        int timedOut = 0;
+        chk(mcn_gate_timed_out(_gate, &timedOut, _stream), "gate state");
+        if (timedOut) throw NetError("a stream gate timed out: the side stream never reached the point the main stream waited for");
+    }
 }
 
 // ---- side-stream submission -----------------------------------------------------------------
+static constexpr int kGateTimeoutMs = 5000;
+bool ConvNet::gatesUsable() const { return _gateOk && !_capturing && !g_noHostWait && !_profiling; }
+void ConvNet::signalGate(int seq) { chk(mcn_stream_signal(_gate, seq, stream()), "stream signal"); }
+void ConvNet::awaitGate(int seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    chk(mcn_stream_gate(_gate, seq, kGateTimeoutMs, _stream), "stream gate");
+    g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 void* ConvNet::stream() const { return t_stream == 1 ? _gradStream : t_stream == 2 ? _commStream : _stream; }
 void* ConvNet::workspace() const { return t_stream == 1 ? _ws2.p : _ws.p; }  // (exchange-thread work uses no workspace)
 
@@ -2327,7 +2366,14 @@ void ConvNet::joinGradWork() {
         _side.wait(_side.pushed());  // the side thread has issued everything it was given
     }
     static const bool joinTick = getenv("MCN_JOIN_TICK") != nullptr;
-    if (joinTick && _tickFlagSide && !_capturing && !g_noHostWait) {
+    if (gatesUsable()) {
+        // the side thread is idle now (waited for above): this thread signals on the side stream and gates its own
+        const int seq = nextGateSeq();
+        const auto t0 = std::chrono::steady_clock::now();
+        chk(mcn_stream_signal(_gate, seq, _gradStream), "stream signal");
+        g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        awaitGate(seq);
+    } else if (joinTick && _tickFlagSide && !_capturing && !g_noHostWait) {
         // (experiment) this thread polls a tick of the side stream instead of queueing a wait on its own stream
         const int tick = ++_tickSeqSide;
         chk(mcn_stream_tick(_tickFlagSide, tick, _gradStream), "stream tick");

@@ -472,11 +472,12 @@ class L2SNCostLayer : public CostLayer {
     DBuf _gathered;          // data-parallel: the all-gathered margin candidates
     void* _evReady = nullptr;  // recorded after the cost launch, on whichever stream ran it
     long _readyTicket = 0;
+    int _readyGateSeq = 0;  // != 0: the statistics are announced by a stream gate signal with this number, not by _evReady
     bool _readyOnExchange = false;
     int _extCount = 0;
     bool _earlyGrad = false;  // this pass already sent its gradient (forward, side stream)
    public:
-    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; }
+    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; _readyGateSeq = 0; }
    protected:
 };
 
@@ -805,6 +806,17 @@ class ConvNet {
     Uploader _uploader;
     std::vector<void*> _forkEvents;
     size_t _forkNext = 0;
+    // side stream -> main stream dependencies (the end-of-step join, the L2-SN statistics) as stream gates instead of event
+    // waits (mcn_stream_gate: the waiting queue resumes one dispatch after the signal instead of 10-15 us after the event)
+    int* _gate = nullptr;
+    int _gateSeq = 0;
+    bool _gateOk = false;
+   public:
+    bool gatesUsable() const;
+    int nextGateSeq() { return ++_gateSeq; }
+    void signalGate(int seq);  // on the calling thread's stream (the side stream)
+    void awaitGate(int seq);   // queued on the main stream
+   private:
     int* _tickFlag = nullptr;  // main stream -> side thread forks as stream ticks (mcn_stream_tick) instead of events
     int _tickSeq = 0;
     int* _tickFlagSide = nullptr;  // side stream -> exchange thread (gradient buckets written by the side stream)

@@ -100,6 +100,22 @@ int mcn_stream_tick(int* flag, int value, void* stream);
  * an armed tick at once; call it before blocking on whoever polls for it. */
 int mcn_arm_tick(int* flag, int value, void* stream);
 int mcn_flush_tick(void);
+/* Stream gates (no counterpart in the reference): a dependency between two streams of ONE device that never passes through
+ * the command processor's barrier packets.  mcn_stream_signal queues a one-thread kernel on the producing stream that
+ * stores `value` (release, device scope) into gate[0]; mcn_stream_gate queues a one-thread kernel on the consuming stream
+ * that spins until (int)(gate[0] - value) >= 0 and then ends, so that everything queued behind it starts.  Measured on
+ * MI355X / ROCm 7.2: a hipStreamWaitEvent whose event has not fired yet holds the waiting queue ~10-15 us after it fires;
+ * a gate holds it for the store to become visible plus one kernel dispatch (tools/step_timeline.py).
+ * A gate that sees nothing for `timeoutMs` gives up, stores 1 into gate[1] (mcn_gate_timed_out) and ends: the grid always
+ * drains.  Gates need the two streams to make progress independently (separate hardware queues); mcn_gate_selftest
+ * queues a gate on `waiter` and then its signal on `signaller` and reports whether the gate was released by the signal
+ * (1) or ran into its timeout (0: use events).  gate: 64 bytes of device memory from mcn_gate_alloc, zero-initialised. */
+int mcn_gate_alloc(int** gate);
+int mcn_gate_free(int* gate);
+int mcn_stream_signal(int* gate, int value, void* stream);
+int mcn_stream_gate(int* gate, int value, int timeoutMs, void* stream);
+int mcn_gate_timed_out(int* gate, int* timedOut, void* stream); /* blocking read of gate[1] */
+int mcn_gate_selftest(int* gate, void* waiter, void* signaller, int* concurrent);
 
 /* Step graphs (no counterpart in the reference, whose step is ~45 launches and several blocking copies per minibatch):
  * everything issued on `stream`, and on streams that join it through events, between begin and end is captured into one
