@@ -336,6 +336,11 @@ struct StripParams {
     int MS, CB, W, stripsPerRow;
     float sO;
     McnTick tick;  // stored by the launch's first thread (MCN_TICK_PROLOGUE)
+    // optional: the strip's share of the shared-bias gradient, sB * sum over the strip's modules and all images of the
+    // gradient rows it stages anyway -> biasPart[strip][F] (the row sum over the whole gradient matrix -- 22 MB for DeepID's
+    // conv1 -- then never runs; the update launch adds the strips' shares, mcn_sgd_plan_build_fused kind 1)
+    float* biasPart;
+    float sB;
 };
 
 template <int KT, int FV>
@@ -403,6 +408,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_strip(const StripParams p) {
 #pragma unroll
         for (int u = 0; u < FV; u++) acc[v][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float bsum = 0.f;  // thread r < HR: running sum of gradient row r (filter r / MS, module r % MS) over the images
+    const bool doBias = p.biasPart != nullptr && blockIdx.y == 0;
     f32x4 ireg[PI], hreg[PH];
     auto load_stage = [&](int st) {
         const unsigned nbyte = (unsigned)st * 128u;
@@ -427,6 +434,14 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_strip(const StripParams p) {
             if (r0 + 32 * q < HR) *reinterpret_cast<f32x4*>(hidT + (size_t)(r0 + 32 * q) * RS + 4 * l8) = hreg[q];
         __syncthreads();
         if (st + 1 < stages) load_stage(st + 1);
+        if (doBias && (int)threadIdx.x < HR) {
+            const float* hr = hidT + (size_t)threadIdx.x * RS;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(hr + 4 * q);
+                bsum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        }
         for (int ms = wave; ms < msCount; ms += 4) {
 #pragma unroll
             for (int i = 0; i < 2; i++) {
@@ -447,6 +462,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad_strip(const StripParams p) {
         }
     }
 
+    if (doBias) {  // modules of the strip in index order
+        __syncthreads();
+        if ((int)threadIdx.x < HR) lds[threadIdx.x] = bsum;
+        __syncthreads();
+        if ((int)threadIdx.x < 16 * FV) {
+            float sum = 0.f;
+            for (int ms = 0; ms < msCount; ms++) sum += lds[threadIdx.x * p.MS + ms];
+            p.biasPart[(size_t)strip * p.F + f0 + threadIdx.x] = p.sB * sum;
+        }
+    }
     // fixed-order sum of the four waves' accumulators: wave 0 + wave 1 + wave 2 + wave 3
     __syncthreads();
     for (int w = 1; w < 4; w++) {
@@ -529,8 +554,10 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
                                          size_t workspaceBytes, int numImages, int imgStride, int imgSizeY,
                                          int imgSizeX, int numImgColors, int numFilters, int filterSize,
                                          int numModulesY, int numModulesX, int paddingStart, int moduleStride,
-                                         int numGroups, float scaleTargets, float scaleOutput, void* stream, int* chunksOut = nullptr) {
+                                         int numGroups, float scaleTargets, float scaleOutput, void* stream, int* chunksOut = nullptr,
+                                         float* biasPart = nullptr, float biasScale = 0.f, int* biasDone = nullptr) {
     // chunksOut: first stage only -- the partials stay in `workspace`, their count goes to *chunksOut, grad is not touched
+    if (biasDone) *biasDone = 0;
     int rc = weight_acts_check(images, hidActs, grad ? grad : (float*)workspace, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
                                numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups);
     if (rc) return rc;
@@ -551,6 +578,8 @@ static int conv_weight_acts_reduced_impl(const float* images, const float* hidAc
         sp.N = numImages; sp.imgStride = imgStride; sp.imgY = imgSizeY; sp.imgX = imgSizeX; sp.C = numImgColors; sp.F = numFilters;
         sp.fs = filterSize; sp.mY = numModulesY; sp.mX = numModulesX; sp.pad = paddingStart; sp.stride = moduleStride;
         sp.MS = pl.MS; sp.CB = pl.CB; sp.W = pl.W; sp.stripsPerRow = pl.stripsPerRow; sp.sO = scaleOutput;
+        sp.biasPart = (chunksOut && biasDone) ? biasPart : nullptr; sp.sB = biasScale;
+        if (sp.biasPart) *biasDone = 1;
         dim3 grid(pl.strips, numImgColors / pl.CB, numFilters / (16 * pl.FV));
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "convWeightActsReduced: grid too large");
         hipStream_t s = (hipStream_t)stream;
@@ -597,7 +626,9 @@ MCN_API int mcn_conv_weight_acts_reduced(const float* images, const float* hidAc
 
 // number of slabs mcn_conv_weight_acts_partials produces for 16-byte aligned operands of this shape
 MCN_API int mcn_conv_weight_acts_partials_count(int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
-                                                int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups) {
+                                                int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups,
+                                                int* biasCapable) {
+    if (biasCapable) *biasCapable = 0;
     if (numImages <= 0 || numImgColors <= 0 || numFilters <= 0 || filterSize <= 0 || numModulesY <= 0 || numModulesX <= 0 || numGroups <= 0 ||
         numImgColors % numGroups != 0)
         return 0;
@@ -605,18 +636,23 @@ MCN_API int mcn_conv_weight_acts_partials_count(int numImages, int imgStride, in
     const StripPlan pl = strip_plan(numImgColors, numFilters, filterSize, numModulesY, numModulesX, moduleStride, numGroups);
     const bool vecn = (numImages % 4 == 0) && (imgStride % 4 == 0);
     const size_t imgBytes = (size_t)numImgColors * imgSizeY * imgSizeX * imgStride * 4, hidBytes = (size_t)numFilters * M * numImages * 4;
-    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31)) return pl.strips;
+    if (pl.ok && moduleStride == 1 && vecn && numImages % 32 == 0 && imgBytes < (1u << 31) && hidBytes < (1u << 31)) {
+        if (biasCapable) *biasCapable = 1;
+        return pl.strips;
+    }
     return divup(M, reduced_modules_per_chunk(M, K, numFilters));
 }
 
 MCN_API int mcn_conv_weight_acts_partials(const float* images, const float* hidActs, void* partials, size_t partialsBytes,
                                           int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
                                           int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
-                                          int numGroups, float scaleOutput, int* numChunks, void* stream) {
+                                          int numGroups, float scaleOutput, int* numChunks, float* biasPartials, float biasScale,
+                                          int* biasDone, void* stream) {
     MCN_REQUIRE(partials && numChunks, "convWeightActsPartials: null pointer");
+    MCN_REQUIRE(!biasPartials || biasDone, "convWeightActsPartials: biasPartials without biasDone");
     return conv_weight_acts_reduced_impl(images, hidActs, nullptr, partials, partialsBytes, numImages, imgStride, imgSizeY, imgSizeX,
                                          numImgColors, numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride,
-                                         numGroups, 0.f, scaleOutput, stream, numChunks);
+                                         numGroups, 0.f, scaleOutput, stream, numChunks, biasPartials, biasScale, biasDone);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -215,6 +215,7 @@ class WeightLayer : public Layer {
     std::vector<std::unique_ptr<Weights>> _weights;
     std::unique_ptr<Weights> _biases;
     DBuf _biasParts;  // stage-1 row sums of the bias gradient (fused update)
+    bool _biasInWgrad = false;  // the weight-gradient launch of input 0 also leaves the bias gradient, in pieces (conv, strip form)
     float _wStep = 0.001f, _bStep = 0.002f;  // layer.cu:294-295
 };
 
@@ -735,8 +736,9 @@ class ConvNet {
     bool _failArmed = false;
     void earlyUpdate();
     void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
-    void finishSideWork();   // end of backward: place the remaining work, then join
-    void joinGradWork();     // run whatever is still deferred on the main stream and wait for the side stream
+    void finishSideWork(bool deferHostWait = false);   // end of backward: place the remaining work, then join
+    void joinGradWork(bool deferHostWait = false);     // run whatever is still deferred on the main stream and wait for the side stream
+    void hostWaitSide();     // the host-side half of a join whose wait was deferred
     int numCases() const { return _numCases; }
     int worldSize() const { return _world; }
     int rank() const { return _rank; }
@@ -811,6 +813,7 @@ class ConvNet {
     int* _gate = nullptr;
     int _gateSeq = 0;
     bool _gateOk = false;
+    bool _sideWaitPending = false;
    public:
     bool gatesUsable() const;
     int nextGateSeq() { return ++_gateSeq; }

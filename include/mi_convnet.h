@@ -214,13 +214,20 @@ int mcn_conv_weight_acts_reduced(const float* images, const float* hidActs, floa
  * temporary, layer.cu:476-485): `partials` receives *numChunks slabs of (filterChannels*fs*fs x numFilters) floats, each
  * scaled by scaleOutput, whose sum over the slabs is the weight gradient; partialsBytes >=
  * mcn_conv_weight_acts_reduced_workspace_bytes(...).  For a consumer that sums them itself (mcn_sgd_plan_build_fused).
- * *numChunks depends only on the layer geometry and on whether numImages is a multiple of 32 (and 16-byte alignment). */
+ * *numChunks depends only on the layer geometry and on whether numImages is a multiple of 32 (and 16-byte alignment):
+ * mcn_conv_weight_acts_partials_count returns it without launching anything.
+ * biasPartials (may be NULL): where the kernel form allows it (*biasDone = 1; *biasCapable of the count query) the launch
+ * also leaves the shared-bias gradient (ConvLayer::bpropBiases, layer.cu:464-474) in pieces, *numChunks slabs of numFilters
+ * floats, each biasScale times the sum of the gradient rows over the slab's modules and all images -- it reads those rows
+ * anyway, and the separate row sum over the whole gradient matrix need not run. */
 int mcn_conv_weight_acts_partials_count(int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
-                                        int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups);
+                                        int filterSize, int numModulesY, int numModulesX, int moduleStride, int numGroups,
+                                        int* biasCapable);
 int mcn_conv_weight_acts_partials(const float* images, const float* hidActs, void* partials, size_t partialsBytes,
                                   int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
                                   int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
-                                  int numGroups, float scaleOutput, int* numChunks, void* stream);
+                                  int numGroups, float scaleOutput, int* numChunks, float* biasPartials, float biasScale,
+                                  int* biasDone, void* stream);
 /* No counterpart in the reference.  mcn_conv_weight_acts_reduced for callers that cannot allocate device memory or
  * bring a workspace (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
  * module-chunk partials live in a static device array of mcn_conv_weight_acts_reduced_static_max_bytes() = 4 MiB

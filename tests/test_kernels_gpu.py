@@ -1065,13 +1065,15 @@ def test_fused_update_finishes_partial_gradients_bitwise(name):
                 L.call('mcn_add_sum_multi', C.cast(ritems, C.c_void_p), 1, bws, bias_bytes, None)
                 L.call('mcn_sgd_update_planned', plan, 3, nb.value, None)
         else:
-            chunks = L.raw('mcn_conv_weight_acts_partials_count')(N, N, imgY, imgX, C_, F, fs, mY, mX, stride, groups)
+            cap = C.c_int(0)
+            chunks = L.raw('mcn_conv_weight_acts_partials_count')(N, N, imgY, imgX, C_, F, fs, mY, mX, stride, groups, C.byref(cap))
             assert chunks > 0
             parts = (Parts * 3)(Parts(wsb.ptr, chunks, 1, 1.0), Parts(bws.ptr, bias_bytes // 4 // rows, 2, 1e-3 / N), Parts(None, 0, 0, 1.0))
             L.call('mcn_sgd_plan_build_fused', C.cast(items, C.c_void_p), C.cast(parts, C.c_void_p), 3, plan, plan.nbytes, C.byref(nb), None)
             for _ in range(2):
                 got = C.c_int(0)
-                call('mcn_conv_weight_acts_partials', img, hid, wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 5e-4 / N, C.byref(got), None)
+                call('mcn_conv_weight_acts_partials', img, hid, wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 5e-4 / N, C.byref(got),
+                     None, 0.0, None, None)
                 assert got.value == chunks
                 pout = (C.c_void_p * 1)(bws.ptr)
                 L.call('mcn_add_sum_multi_stage1', C.cast(ritems, C.c_void_p), 1, pout, None)
@@ -1080,3 +1082,34 @@ def test_fused_update_finishes_partial_gradients_bitwise(name):
     for a, b, what in zip(out[0], out[1], ('W', 'inc', 'grad', 'bias', 'biasInc', 'biasGrad', 'other', 'otherInc')):
         assert np.array_equal(a, b), '%s: %s differs between the fused and the separate tail' % (name, what)
     assert np.abs(out[0][2]).max() > 0 and np.abs(out[0][5]).max() > 0
+
+
+@pytest.mark.parametrize('name', ['conv1_55', 'conv1_39x31', 'conv1_plus', 'cifar_conv1', 'conv2'])
+def test_conv_weight_acts_partials_leave_the_bias_gradient_in_pieces(name):
+    """Where the strip form runs (first-layer shapes) the launch also sums the gradient rows it stages: slabs of numFilters
+    floats whose sum is ConvLayer::bpropBiases' row sum (layer.cu:464-474) at the kernel tolerance; elsewhere it says so."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 128
+    rng = np.random.default_rng(78)
+    img, hid = mk(rng, C_ * imgY * imgX, N), mk(rng, F * mY * mX, N)
+    L = capi.lib()
+    cap = C.c_int(-1)
+    chunks = L.raw('mcn_conv_weight_acts_partials_count')(N, N, imgY, imgX, C_, F, fs, mY, mX, stride, groups, C.byref(cap))
+    nbytes = ws_bytes('mcn_conv_weight_acts_reduced_workspace_bytes', C_, F, fs, mY, mX, groups)
+    wsb = capi.workspace(nbytes)
+    bias = dev_empty((chunks * F,), np.nan)
+    got, done = C.c_int(0), C.c_int(-1)
+    call('mcn_conv_weight_acts_partials', dev(img), dev(hid), wsb, nbytes, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 5e-4 / N,
+         C.byref(got), bias, 2e-3 / N, C.byref(done), None)
+    assert got.value == chunks and done.value == cap.value
+    K = (C_ // groups) * fs * fs
+    parts = wsb.numpy(shape=(chunks * K * F,), dtype=np.float32).reshape(chunks, K * F)
+    want = O.weight_acts(img, hid, N, partial_sum=0, conv=True, sO=5e-4 / N, **geo_kw(g))
+    close(parts.astype(np.float64).sum(0).astype(np.float32).reshape(K, F), want, what=name + ' weight gradient from the slabs')
+    if name.startswith('conv1') or name == 'cifar_conv1':
+        assert done.value == 1, 'first-layer shapes take the strip form'
+    if done.value:
+        wb = np.zeros(F, np.float32)
+        O.add_sum(wb, hid, F, mY * mX * N, 1, 0.0, 2e-3 / N)
+        close(bias.numpy().reshape(chunks, F).astype(np.float64).sum(0).astype(np.float32), wb, what=name + ' bias gradient from the slabs')
