@@ -44,12 +44,16 @@ static inline uint64_t mcn_now_ns() {
 // everything queued before it on its stream has finished.  Any other launch leaves the tick armed and mcn_launch_check sends it
 // with a one-thread kernel right behind that launch.
 struct McnTick {
-    int* flag;
+    int* flag;  // host-visible word (a submitting thread polls it)
+    int* gate;  // optional device word (a stream gate on another stream spins on it, mcn_stream_gate)
     int value;
 };
 McnTick mcn_take_tick(hipStream_t stream);  // {nullptr, 0} when nothing is armed for that stream
-#define MCN_TICK_PROLOGUE(p)                                                                                          \
-    if ((p).tick.flag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) *(volatile int*)(p).tick.flag = (p).tick.value
+#define MCN_TICK_PROLOGUE(p)                                                                          \
+    if ((p).tick.flag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) {           \
+        if ((p).tick.gate) *(volatile int*)(p).tick.gate = (p).tick.value;                            \
+        *(volatile int*)(p).tick.flag = (p).tick.value;                                               \
+    }
 
 static inline int divup(int a, int b) { return (a + b - 1) / b; }
 static inline size_t divup_sz(size_t a, size_t b) { return (a + b - 1) / b; }

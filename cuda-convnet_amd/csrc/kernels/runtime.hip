@@ -31,10 +31,11 @@ int mcn_check_hip(hipError_t e, const char* what) {
 
 static thread_local struct {
     int* flag = nullptr;
+    int* gate = nullptr;
     int value = 0;
     hipStream_t stream = nullptr;
 } t_tick;
-__global__ void k_stream_tick(volatile int* flag, int value);
+__global__ void k_stream_tick(volatile int* flag, int value, volatile int* gate);
 static std::atomic<long> g_tickSent[4];
 static void tick_send_now(int why = 0) {
     if (!t_tick.flag) return;
@@ -44,13 +45,14 @@ static void tick_send_now(int why = 0) {
         (void)reg;
         g_tickSent[why]++;
     }
-    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value);
+    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, t_tick.stream, (volatile int*)t_tick.flag, t_tick.value, (volatile int*)t_tick.gate);
     t_tick.flag = nullptr;
 }
 McnTick mcn_take_tick(hipStream_t stream) {
-    McnTick t = {nullptr, 0};
+    McnTick t = {nullptr, nullptr, 0};
     if (t_tick.flag && t_tick.stream == stream) {
         t.flag = t_tick.flag;
+        t.gate = t_tick.gate;
         t.value = t_tick.value;
         t_tick.flag = nullptr;
     }
@@ -207,14 +209,19 @@ MCN_API int mcn_graph_destroy(void* graphExec) {
 // for the event's marker packet (tools/event_poll_probe.hip, MI355X / ROCm 7.2: 20 x 10 us kernels take 225 us back to
 // back, 255 us with a tick after each, 285 us with an event after each).
 // ---------------------------------------------------------------------------
-__global__ void k_stream_tick(volatile int* flag, int value) { *flag = value; }
+__global__ void k_stream_tick(volatile int* flag, int value, volatile int* gate) {
+    if (gate) *gate = value;
+    *flag = value;
+}
 // The tick rides on this thread's NEXT launch: in the first instructions of a kernel that has a tick slot (the classifier
 // products, the multi-input backward-data product, imgActs, the strip weight gradient), else in a one-thread kernel behind
 // it.  mcn_flush_tick sends an armed tick at once (before the caller blocks on whoever waits for it).
-MCN_API int mcn_arm_tick(int* flag, int value, void* stream) {
+MCN_API int mcn_arm_tick(int* flag, int value, void* stream) { return mcn_arm_tick_gate(flag, nullptr, value, stream); }
+MCN_API int mcn_arm_tick_gate(int* flag, int* gate, int value, void* stream) {
     MCN_REQUIRE(flag, "armTick: null pointer");
     tick_send_now(2);  // (an older one first: ticks of a stream stay in order)
     t_tick.flag = flag;
+    t_tick.gate = gate;
     t_tick.value = value;
     t_tick.stream = (hipStream_t)stream;
     return MCN_OK;
@@ -233,7 +240,7 @@ MCN_API int mcn_tick_free(int* flag) { return flag ? mcn_check_hip(hipHostFree(f
 MCN_API int mcn_stream_tick(int* flag, int value, void* stream) {
     MCN_REQUIRE(flag, "streamTick: null pointer");
     tick_send_now(3);  // (an armed one first: ticks stay in order)
-    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value);
+    MCN_LAUNCH(k_stream_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, (volatile int*)flag, value, (volatile int*)nullptr);
     return mcn_check_hip(hipGetLastError(), "streamTick");
 }
 

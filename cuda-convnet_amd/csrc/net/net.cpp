@@ -1622,6 +1622,7 @@ ConvNet::~ConvNet() {
     if (_gradStream) mcn_stream_destroy(_gradStream);
     for (void* e : _forkEvents) mcn_event_destroy(e);
     if (_gate) mcn_gate_free(_gate);
+    if (_forkGate) mcn_gate_free(_forkGate);
     if (_tickFlag) mcn_tick_free(_tickFlag);
     if (_tickFlagSide) mcn_tick_free(_tickFlagSide);
     if (_evJoin) mcn_event_destroy(_evJoin);
@@ -1795,6 +1796,7 @@ void ConvNet::resetAfterError() {
     mcn_device_sync();  // (a sticky device error shows up in the next call's status)
     if (_gate && _gateOk) {  // a gate that did run into its timeout has been reported with this error: start clean
         mcn_memset(_gate + 1, 0, sizeof(int), _stream);
+        if (_forkGate) mcn_memset(_forkGate + 1, 0, sizeof(int), _stream);
         mcn_stream_sync(_stream);
     }
 }
@@ -1825,6 +1827,11 @@ void ConvNet::initDevice() {  // convnet.cu:139-145
             int ok = 0;
             chk(mcn_gate_selftest(_gate, _stream, _gradStream, &ok), "gate self-test");
             _gateOk = ok != 0;  // (two streams on one hardware queue: a gate would only ever time out -- events then)
+            if (_gateOk && _tickFlag && getenv("MCN_NO_FORK_GATES") == nullptr) {
+                chk(mcn_gate_alloc(&_forkGate), "gate");
+                chk(mcn_gate_selftest(_forkGate, _gradStream, _stream, &ok), "gate self-test");
+                _forkGateOk = ok != 0;
+            }
             if (getenv("MCN_DEBUG_TIMES")) fprintf(stderr, "[mcn] stream gates: %s\n", _gateOk ? "on" : "off (streams share a hardware queue)");
         }
     }
@@ -1982,16 +1989,19 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
 void ConvNet::sync() {
     joinGradWork();
     chk(mcn_stream_sync(_stream), "sync");
-    if (_gate && _gateOk) {
+    for (int* g : {_gateOk ? _gate : nullptr, _forkGateOk ? _forkGate : nullptr}) {
+        if (!g) continue;
         int timedOut = 0;
-        chk(mcn_gate_timed_out(_gate, &timedOut, _stream), "gate state");
-        if (timedOut) throw NetError("a stream gate timed out: the side stream never reached the point the main stream waited for");
+        chk(mcn_gate_timed_out(g, &timedOut, _stream), "gate state");
+        if (timedOut) throw NetError("a stream gate timed out: one stream never reached the point the other waited for");
     }
 }
 
 // ---- side-stream submission -----------------------------------------------------------------
 static constexpr int kGateTimeoutMs = 5000;
-bool ConvNet::gatesUsable() const { return _gateOk && !_capturing && !g_noHostWait && !_profiling; }
+// (not for data-parallel replicas: RCCL brings streams of its own, and streams that end up sharing a hardware queue would turn
+// a gate into its timeout; their joins stay events)
+bool ConvNet::gatesUsable() const { return _gateOk && !_dpOn && !_capturing && !g_noHostWait && !_profiling; }
 void ConvNet::signalGate(int seq) { chk(mcn_stream_signal(_gate, seq, stream()), "stream signal"); }
 void ConvNet::awaitGate(int seq) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -2213,6 +2223,7 @@ void ConvNet::flushSideWork(size_t count) {
     const bool ticks = _tickFlag && !_capturing && !g_noHostWait && t_stream == 0;  // (only the thread that feeds a stream ticks it)
     void* forkEvent = nullptr;
     int tick = 0;
+    bool gateFork = false;
     if (ticks) {
         // a one-thread kernel that writes a sequence number the side thread polls for: seen 5 us earlier than the event,
         // and half the bubble on this stream (tools/event_poll_probe.hip)
@@ -2222,8 +2233,9 @@ void ConvNet::flushSideWork(size_t count) {
         tick = ++_tickSeq;
         static const bool ownKernel = getenv("MCN_TICK_KERNEL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
+        gateFork = _forkGateOk && !ownKernel && !_dpOn;
         if (ownKernel) chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
-        else chk(mcn_arm_tick(_tickFlag, tick, _stream), "arm tick");
+        else chk(mcn_arm_tick_gate(_tickFlag, gateFork ? _forkGate : nullptr, tick, _stream), "arm tick");
         g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     } else {
         forkEvent = _forkEvents[_forkNext++ % _forkEvents.size()];
@@ -2252,10 +2264,11 @@ void ConvNet::flushSideWork(size_t count) {
         t_stream = 0;
         return;
     }
-    _side.push([this, forkEvent, tick, fns] {
+    _side.push([this, forkEvent, tick, gateFork, fns] {
         t_stream = 1;
         const auto t0 = std::chrono::steady_clock::now();
         if (forkEvent) chk(timedStreamWait(_gradStream, forkEvent), "wait event");
+        else if (gateFork) chk(mcn_stream_gate(_forkGate, tick, kGateTimeoutMs, _gradStream), "stream gate (fork)");
         else awaitTick(tick);
         const auto t1 = std::chrono::steady_clock::now();
         const uint64_t l0 = mcn_launch_ns();

@@ -811,6 +811,9 @@ class ConvNet {
     // side stream -> main stream dependencies (the end-of-step join, the L2-SN statistics) as stream gates instead of event
     // waits (mcn_stream_gate: the waiting queue resumes one dispatch after the signal instead of 10-15 us after the event)
     int* _gate = nullptr;
+    int* _forkGate = nullptr;  // main stream -> side stream: the fork ticks' device word; the side thread queues a gate on the side
+                               // stream instead of polling the host word (it never blocks, and neither does the main thread for it)
+    bool _forkGateOk = false;
     int _gateSeq = 0;
     bool _gateOk = false;
     bool _sideWaitPending = false;

@@ -99,6 +99,9 @@ int mcn_stream_tick(int* flag, int value, void* stream);
  * before it on its stream has finished -- and any other launch is followed by a one-thread tick kernel.  mcn_flush_tick sends
  * an armed tick at once; call it before blocking on whoever polls for it. */
 int mcn_arm_tick(int* flag, int value, void* stream);
+/* ... and the same value into gate[0] (device memory, mcn_gate_alloc) as well: what a stream gate on another stream waits
+ * for (mcn_stream_gate) -- a fork that needs neither a host thread's poll nor a barrier packet */
+int mcn_arm_tick_gate(int* flag, int* gate, int value, void* stream);
 int mcn_flush_tick(void);
 /* Stream gates (no counterpart in the reference): a dependency between two streams of ONE device that never passes through
  * the command processor's barrier packets.  mcn_stream_signal queues a one-thread kernel on the producing stream that
