@@ -324,6 +324,25 @@ def main():
             v.sort(key=lambda x: x[1] / max(x[0], 1))
             prof[k] = v[len(v) // 2]
             prof_min[k] = v[0][1] / max(v[0][0], 1) * 1e3
+    rccl = None
+    if world > 1 or a.force_dp:
+        # what the replica group's communicator says about itself (ncclCommCount: the ranks RCCL saw, not the ranks the
+        # launcher started), the buckets of one step, and the collectives' time on the exchange stream (events around every
+        # call, in an untimed extra block)
+        nranks, ver, is_rccl = lib.commInfo()
+        lib.getCommLog()
+        lib.startSteps(a.profile_steps, 0, 3)
+        lib.finishBatch()
+        cp = lib.getProfile()
+        log = lib.getCommLog()
+        per = max(len(log) // max(a.profile_steps, 1), 1)
+        step0 = log[:per]
+        rccl = {'nranks': nranks, 'version': ver, 'transport': 'rccl' if is_rccl else 'shared-memory rehearsal (test build)',
+                'buckets_bytes': [4 * c for k, o, c in step0 if k == 'allreduce'],
+                'allgather_bytes_per_rank': [4 * c for k, o, c in step0 if k == 'allgather'],
+                'allreduce_us_per_step': round(cp.get('comm.allreduce', (0, 0.0))[1] * 1e3 / max(a.profile_steps, 1), 2),
+                'allgather_us_per_step': round(cp.get('comm.allgather', (0, 0.0))[1] * 1e3 / max(a.profile_steps, 1), 2),
+                'collectives_per_step': per}
     breakdown = None
     if world == 1 and not a.no_profile:
         lib.startSteps(a.steps, 0, 0)
@@ -383,6 +402,11 @@ def main():
             out['upload_inclusive'] = inclusive
         if breakdown:
             out['host_breakdown_us_per_step'] = breakdown
+        if rccl:
+            out['rccl'] = rccl
+            if rccl['transport'] != 'rccl':  # a rehearsal of the launch line on one GPU: not a measurement of anything
+                out['rehearsal_images_per_sec'] = out['value']
+                out['value'] = None
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.workload)
         sys.stdout.flush()

@@ -34,13 +34,21 @@ class _CheckpointUnpickler(pickle.Unpickler):
         raise pickle.UnpicklingError('checkpoint refers to %s.%s: not a plain weights checkpoint' % (module, name))
 
 
-def import_native():
+def import_native(hooks=None):
+    """The `_ConvNet` extension.  hooks=True (or MCN_USE_TEST_HOOKS=1 in the environment): the TEST build `_ConvNetHooks`
+    instead -- same sources plus the shared-memory rehearsal communicator (MCN_COMM=shm) and failNextBackwardAt, which the
+    product binaries do not contain."""
+    if hooks is None:
+        hooks = os.environ.get('MCN_USE_TEST_HOOKS') == '1'
     try:
-        from . import _ConvNet
+        if hooks:
+            from . import _ConvNetHooks as mod
+        else:
+            from . import _ConvNet as mod
     except ImportError as e:  # fail loudly: the HIP path is the product
-        raise ImportError('cuda_convnet_amd._ConvNet is not built (make -C cuda-convnet_amd/csrc, or '
-                          '__graft_entry__.build()): %s' % e)
-    return _ConvNet
+        raise ImportError('cuda_convnet_amd.%s is not built (make -C cuda-convnet_amd/csrc, or '
+                          '__graft_entry__.build()): %s' % ('_ConvNetHooks' if hooks else '_ConvNet', e))
+    return mod
 
 
 class ConvNet:

@@ -323,6 +323,8 @@ static struct {
     int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
     int (*GroupStart)();
     int (*GroupEnd)();
+    int (*CommCount)(rcclComm_t, int*);
+    int (*GetVersion)(int*);
     const char* (*GetErrorString)(int);
 } g_rccl;
 
@@ -353,6 +355,8 @@ static int rccl_load() {
     BIND(GroupEnd, "ncclGroupEnd");
     BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+    *(void**)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");  // (optional: only reported)
+    *(void**)(&g_rccl.GetVersion) = dlsym(h, "ncclGetVersion");
     g_rccl.handle = h;
     return MCN_OK;
 }
@@ -364,13 +368,21 @@ static int rccl_check(int rc, const char* what) {
 }
 
 // ---------------------------------------------------------------------------
-// Rehearsal communicator for ranks that SHARE one GPU (MCN_COMM=shm).  RCCL refuses a second rank on a device
+// Rehearsal communicator for ranks that SHARE one GPU (MCN_COMM=shm) -- TEST BUILD ONLY (-DMCN_TEST_HOOKS,
+// libmiconvnet_hooks.so): the product library does not contain it.  RCCL refuses a second rank on a device
 // ("duplicate GPU"), so a one-GPU box can never run the data-parallel step with world > 1.  This transport lets it:
-// same entry points, same stream-ordered meaning, the payload staged through a POSIX shared-memory segment
-// (stream sync -> D2H into the rank's slot -> barrier -> every rank adds the slots in rank order -> H2D -> sync).
+// same entry points, same stream-ordered, ASYNCHRONOUS meaning as RCCL -- a call only queues work on the stream and
+// returns: D2H into the rank's slot -> host function (barrier; every rank adds the slots in rank order) -> H2D ->
+// host function (barrier: nobody overwrites a slot before every rank has read it).  Nothing in it blocks the calling
+// thread, so an ordering hazard between the exchange stream and the compute streams shows up exactly as it would with RCCL.
 // The sum has a fixed order, so all ranks end with bit-identical buffers, as with RCCL's ring on identical inputs.
-// It is a test transport (two PCIe trips and a host sum per collective) and is never selected unless asked for.
 // ---------------------------------------------------------------------------
+struct ShmComm;
+struct McnComm {
+    rcclComm_t rccl = nullptr;
+    ShmComm* shm = nullptr;
+};
+#ifdef MCN_TEST_HOOKS
 struct ShmHeader {
     std::atomic<uint32_t> arrived, generation, attached;
     uint32_t numRanks;
@@ -383,10 +395,7 @@ struct ShmComm {
     char* slots = nullptr;
     float* bounce = nullptr;  // page-locked, slotBytes
     char name[96] = {0};
-};
-struct McnComm {
-    rcclComm_t rccl = nullptr;
-    ShmComm* shm = nullptr;
+    std::atomic<int> failed{0};  // a barrier inside a host function timed out: reported by the next call
 };
 static const char kShmTag[] = "MCNSHM:";
 static const size_t kShmSlotBytes = 8u << 20;
@@ -467,36 +476,70 @@ static int shm_init(McnComm* mc, int numRanks, int rank, const char* name) {
     }
     if (rank == 0) shm_unlink(c->name);  // everyone holds a mapping: the name can go
     int rc = mcn_check_hip(hipHostMalloc((void**)&c->bounce, c->slotBytes, hipHostMallocDefault), "hipHostMalloc");
-    if (rc) return rc;
+    if (rc) {
+        munmap(m, c->mapBytes);
+        delete c;
+        return rc;
+    }
     mc->shm = c;
     return MCN_OK;
 }
 
-// one chunk of at most slotBytes: buf[0..n) <- sum over ranks (rank order) / recv <- concatenation
+// Host functions of one chunk, run by the stream in order (hipLaunchHostFunc); they may block (barriers with the peers)
+// but never the thread that queued them.
+struct ShmStep {
+    ShmComm* c;
+    size_t n;
+    bool gather, last;
+};
+static void shm_host_reduce(void* arg) {
+    ShmStep* st = (ShmStep*)arg;
+    ShmComm* c = st->c;
+    if (shm_barrier(c, "collective (shm)")) c->failed.store(1);  // every rank's slot is filled
+    if (!st->gather) {
+        const float* s0 = (const float*)c->slots;
+        for (size_t i = 0; i < st->n; i++) c->bounce[i] = s0[i];
+        for (int r = 1; r < c->numRanks; r++) {
+            const float* sr = (const float*)(c->slots + (size_t)r * c->slotBytes);
+            for (size_t i = 0; i < st->n; i++) c->bounce[i] += sr[i];
+        }
+        if (shm_barrier(c, "collective (shm)")) c->failed.store(1);  // every rank has read the slots: they may be refilled
+    }
+}
+static void shm_host_release(void* arg) {
+    ShmStep* st = (ShmStep*)arg;
+    if (st->gather && shm_barrier(st->c, "collective (shm)")) st->c->failed.store(1);  // every rank has copied the slots out
+    delete st;
+}
+
+// one chunk of at most slotBytes: recv[0..n) <- sum over ranks (rank order) / recv <- concatenation; only queues work on s
 static int shm_exchange(ShmComm* c, const float* send, float* recv, size_t n, bool gather, hipStream_t s, const char* what) {
+    if (c->failed.load()) {
+        mcn_set_error("%s: an earlier collective timed out waiting for a peer (shared-memory communicator)", what);
+        return MCN_ERCCL;
+    }
+    ShmStep* st = new ShmStep{c, n, gather, true};
     int rc = mcn_check_hip(hipMemcpyAsync(c->slots + (size_t)c->rank * c->slotBytes, send, n * 4, hipMemcpyDeviceToHost, s), what);
-    if (!rc) rc = mcn_check_hip(hipStreamSynchronize(s), what);
-    if (rc) return rc;
-    if ((rc = shm_barrier(c, what))) return rc;
+    if (!rc) rc = mcn_check_hip(hipLaunchHostFunc(s, shm_host_reduce, st), what);
     if (gather) {
         for (int r = 0; r < c->numRanks && !rc; r++)
             rc = mcn_check_hip(hipMemcpyAsync(recv + (size_t)r * n, c->slots + (size_t)r * c->slotBytes, n * 4, hipMemcpyHostToDevice, s), what);
-    } else {
-        const float* s0 = (const float*)c->slots;
-        for (size_t i = 0; i < n; i++) c->bounce[i] = s0[i];
-        for (int r = 1; r < c->numRanks; r++) {
-            const float* sr = (const float*)(c->slots + (size_t)r * c->slotBytes);
-            for (size_t i = 0; i < n; i++) c->bounce[i] += sr[i];
-        }
+    } else if (!rc) {
         rc = mcn_check_hip(hipMemcpyAsync(recv, c->bounce, n * 4, hipMemcpyHostToDevice, s), what);
     }
-    if (!rc) rc = mcn_check_hip(hipStreamSynchronize(s), what);
-    if (rc) return rc;
-    return shm_barrier(c, what);  // nobody overwrites a slot before every rank has read it
+    if (!rc) rc = mcn_check_hip(hipLaunchHostFunc(s, shm_host_release, st), what);
+    return rc;
 }
+#endif  // MCN_TEST_HOOKS
 
 MCN_API int mcn_comm_unique_id(char idBytes[128]) {
     const char* kind = getenv("MCN_COMM");
+#ifndef MCN_TEST_HOOKS
+    if (kind && strcmp(kind, "shm") == 0) {
+        mcn_set_error("MCN_COMM=shm: the rehearsal communicator is only in the test build (libmiconvnet_hooks.so)");
+        return MCN_ERCCL;
+    }
+#else
     if (kind && strcmp(kind, "shm") == 0) {
         memset(idBytes, 0, 128);
         unsigned long long r = 0;
@@ -506,6 +549,7 @@ MCN_API int mcn_comm_unique_id(char idBytes[128]) {
         snprintf(idBytes, 128, "%s/mcn_%d_%016llx", kShmTag, (int)getpid(), r);
         return MCN_OK;
     }
+#endif
     int rc = rccl_load();
     if (rc) return rc;
     rcclUniqueId id;
@@ -519,9 +563,12 @@ MCN_API int mcn_comm_init(void** comm, int numRanks, int rank, const char idByte
     MCN_REQUIRE(comm && idBytes && numRanks >= 1 && rank >= 0 && rank < numRanks, "mcn_comm_init: bad argument");
     McnComm* mc = new McnComm;
     int rc;
+#ifdef MCN_TEST_HOOKS
     if (strncmp(idBytes, kShmTag, sizeof(kShmTag) - 1) == 0 && memchr(idBytes, 0, 128)) {
         rc = shm_init(mc, numRanks, rank, idBytes + sizeof(kShmTag) - 1);
-    } else {
+    } else
+#endif
+    {
         rc = rccl_load();
         if (!rc) {
             rcclUniqueId id;
@@ -542,11 +589,15 @@ MCN_API int mcn_comm_destroy(void* comm) {
     McnComm* mc = (McnComm*)comm;
     if (!mc) return MCN_OK;
     int rc = MCN_OK;
+#ifdef MCN_TEST_HOOKS
     if (mc->shm) {
+        (void)hipDeviceSynchronize();  // (host functions of queued collectives still hold the segment)
         if (mc->shm->bounce) (void)hipHostFree(mc->shm->bounce);
         munmap(mc->shm->hdr, mc->shm->mapBytes);
         delete mc->shm;
-    } else if (mc->rccl && g_rccl.handle) {
+    } else
+#endif
+    if (mc->rccl && g_rccl.handle) {
         rc = rccl_check(g_rccl.CommDestroy(mc->rccl), "ncclCommDestroy");
     }
     delete mc;
@@ -557,6 +608,7 @@ MCN_API int mcn_comm_destroy(void* comm) {
 MCN_API int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream) {
     McnComm* mc = (McnComm*)comm;
     MCN_REQUIRE(mc && buf, "mcn_allreduce_sum: communicator not initialised");
+#ifdef MCN_TEST_HOOKS
     if (mc->shm) {
         const size_t per = mc->shm->slotBytes / 4;
         for (size_t off = 0; off < count; off += per)
@@ -564,6 +616,7 @@ MCN_API int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream
                 return rc;
         return MCN_OK;
     }
+#endif
     MCN_REQUIRE(g_rccl.handle && mc->rccl, "mcn_allreduce_sum: communicator not initialised");
     return rccl_check(g_rccl.AllReduce(buf, buf, count, 7, 0, mc->rccl, (hipStream_t)stream), "ncclAllReduce");
 }
@@ -571,13 +624,37 @@ MCN_API int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream
 MCN_API int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream) {
     McnComm* mc = (McnComm*)comm;
     MCN_REQUIRE(mc && send && recv, "mcn_allgather: communicator not initialised");
+#ifdef MCN_TEST_HOOKS
     if (mc->shm) {
         MCN_REQUIRE(countPerRank * 4 <= mc->shm->slotBytes, "mcn_allgather: more than %zu bytes per rank (shared-memory communicator)",
                     mc->shm->slotBytes);
         return shm_exchange(mc->shm, send, recv, countPerRank, true, (hipStream_t)stream, "allgather (shm)");
     }
+#endif
     MCN_REQUIRE(g_rccl.handle && mc->rccl, "mcn_allgather: communicator not initialised");
     return rccl_check(g_rccl.AllGather(send, recv, countPerRank, 7, mc->rccl, (hipStream_t)stream), "ncclAllGather");
+}
+
+// what the communicator is: ranks RCCL itself counts (ncclCommCount), RCCL's version code, 1 = RCCL / 0 = the test build's
+// rehearsal transport
+MCN_API int mcn_comm_info(void* comm, int* numRanks, int* version, int* isRccl) {
+    McnComm* mc = (McnComm*)comm;
+    MCN_REQUIRE(mc && numRanks && version && isRccl, "mcn_comm_info: bad argument");
+    *numRanks = 0; *version = 0; *isRccl = 0;
+#ifdef MCN_TEST_HOOKS
+    if (mc->shm) {
+        *numRanks = mc->shm->numRanks;
+        return MCN_OK;
+    }
+#endif
+    MCN_REQUIRE(g_rccl.handle && mc->rccl, "mcn_comm_info: communicator not initialised");
+    *isRccl = 1;
+    if (g_rccl.CommCount) {
+        int rc = rccl_check(g_rccl.CommCount(mc->rccl, numRanks), "ncclCommCount");
+        if (rc) return rc;
+    }
+    if (g_rccl.GetVersion) return rccl_check(g_rccl.GetVersion(version), "ncclGetVersion");
+    return MCN_OK;
 }
 
 // collectives issued between the two calls are fused by RCCL into one launch

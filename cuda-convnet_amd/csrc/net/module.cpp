@@ -10,7 +10,8 @@
 //   startSteps(n, test=0, profile=0)     n minibatch steps cycling over the resident batch (finishBatch collects)
 //   getProfile()                         per-operation device time of the last profiled startSteps
 //   getCommLog() / getGradSegments()     the data-parallel exchange as it was issued, and the arena layout (tests)
-//   failNextBackwardAt(layerName)        one injected failure in the middle of the next backward pass (tests)
+//   commInfo()                           what the replica group's communicator reports about itself
+//   failNextBackwardAt(layerName)        TEST BUILD ONLY (_ConvNetHooks): one injected failure in the next backward pass
 // Differences from the reference that a caller can observe: errors raise RuntimeError
 // instead of exit(1)/assert; checkGradients returns its per-matrix results instead of
 // printing and calling exit(0); the GIL is released while a call blocks.
@@ -430,14 +431,28 @@ static PyObject* getGradSegments(PyObject*, PyObject*) {
     return Py_BuildValue("Nn", out, (Py_ssize_t)model->bucketFloats());
 }
 
-// failNextBackwardAt(layerName): the next backward pass throws when it reaches that weight layer -- after the layers above
-// it have queued their work on both streams (tests of the recovery after a failed step)
+#ifdef MCN_TEST_HOOKS
+// TEST BUILD ONLY (_ConvNetHooks): failNextBackwardAt(layerName): the next backward pass throws when it reaches that weight
+// layer -- after the layers above it have queued their work on both streams (tests of the recovery after a failed step)
 static PyObject* failNextBackwardAt(PyObject*, PyObject* args) {
     const char* name = nullptr;
     if (!PyArg_ParseTuple(args, "s", &name)) return nullptr;
     if (!needModel()) return nullptr;
     model->failNextBackwardAt(name);
     Py_RETURN_NONE;
+}
+#endif
+
+static PyObject* commInfo(PyObject*, PyObject*) {
+    if (!needModel()) return nullptr;
+    int n = 0, v = 0, r = 0;
+    try {
+        model->commInfo(n, v, r);
+    } catch (std::exception& e) {
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return nullptr;
+    }
+    return Py_BuildValue("(iii)", n, v, r);
 }
 
 static PyMethodDef methods[] = {
@@ -457,13 +472,20 @@ static PyMethodDef methods[] = {
     {"initDataParallel", initDataParallel, METH_VARARGS, "initDataParallel(rank, worldSize, uniqueId, force=0)"},
     {"getCommLog", getCommLog, METH_NOARGS, "getCommLog() -> [(kind, arenaOffset, count)] issued since the last call (data parallel)"},
     {"getGradSegments", getGradSegments, METH_NOARGS, "getGradSegments() -> ([(layer, begin, end)] in arena order, bucketFloats)"},
+#ifdef MCN_TEST_HOOKS
     {"failNextBackwardAt", failNextBackwardAt, METH_VARARGS, "failNextBackwardAt(layerName): inject one failure into the next backward pass (tests)"},
+#endif
+    {"commInfo", commInfo, METH_NOARGS, "commInfo() -> (ranks the communicator counts, RCCL version code, 1 if RCCL)"},
     {"destroyModel", destroyModel, METH_NOARGS, "destroyModel()"},
     {nullptr, nullptr, 0, nullptr}};
 
+#ifdef MCN_TEST_HOOKS  // the test build is a module of its own: a process cannot mistake one for the other
+static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_ConvNetHooks", "MI355X-native cuda-convnet compute core (test build with hooks)", -1, methods};
+PyMODINIT_FUNC PyInit__ConvNetHooks(void) {
+#else
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_ConvNet", "MI355X-native cuda-convnet compute core", -1, methods};
-
 PyMODINIT_FUNC PyInit__ConvNet(void) {
+#endif
     import_array();
     return PyModule_Create(&moduledef);
 }

@@ -1628,6 +1628,7 @@ ConvNet::~ConvNet() {
     if (_evJoin) mcn_event_destroy(_evJoin);
     if (_stream) mcn_stream_destroy(_stream);
     for (void* e : _eventPool) mcn_event_destroy(e);
+    for (void* e : _commEventPool) mcn_event_destroy(e);
 }
 
 // Fused epilogues, decided once from the graph (no counterpart in the reference, which launches
@@ -1986,6 +1987,11 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     }
 }
 
+void ConvNet::commInfo(int& numRanks, int& version, int& isRccl) {
+    if (!_comm) throw NetError("no replica group (initDataParallel has not been called)");
+    chk(mcn_comm_info(_comm, &numRanks, &version, &isRccl), "comm info");
+}
+
 void ConvNet::sync() {
     joinGradWork();
     chk(mcn_stream_sync(_stream), "sync");
@@ -2125,7 +2131,8 @@ void ConvNet::flushBiasSums(int which) {
 }
 
 bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
-    if (_failArmed) {  // (set by bprop from failNextBackwardAt: test hook)
+#ifdef MCN_TEST_HOOKS
+    if (_failArmed) {  // (set by bprop from failNextBackwardAt)
         std::lock_guard<std::mutex> lk(_failMutex);
         if (wl->name() == _failAt) {
             _failAt.clear();
@@ -2133,6 +2140,7 @@ bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
             throw NetError("injected failure at layer '" + wl->name() + "'");
         }
     }
+#endif
     _passNow.push_back(wl);
     return ++_wlSeen == _wlPerPass;
 }
@@ -2326,11 +2334,45 @@ std::vector<ConvNet::SegmentInfo> ConvNet::gradSegments() {
     return out;
 }
 
+void* ConvNet::commEvent() {  // exchange thread only
+    if (_commEventsUsed == _commEventPool.size()) {
+        void* e = nullptr;
+        chk(mcn_event_create(&e), "event create");
+        _commEventPool.push_back(e);
+    }
+    return _commEventPool[_commEventsUsed++];
+}
+
+void ConvNet::commCollect(std::map<std::string, ProfEntry>& into) {  // worker thread, exchange thread idle, device drained
+    for (const CommSpan& s : _commSpans) {
+        float ms = 0;
+        chk(mcn_event_elapsed_ms(&ms, s.e0, s.e1), "event elapsed");
+        ProfEntry& e = into[s.kind == 0 ? "comm.allreduce" : "comm.allgather"];
+        e.count++;
+        e.ms += ms;
+        ProfEntry& b = into[s.kind == 0 ? "comm.allreduce_floats" : "comm.allgather_floats"];
+        b.count++;
+        b.ms += (double)s.count;  // (a count carried in the ms field: floats moved per rank)
+    }
+    _commSpans.clear();
+    _commEventsUsed = 0;
+}
+
 void ConvNet::gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
+    void *e0 = nullptr, *e1 = nullptr;
+    if (_commTiming) {
+        e0 = commEvent();
+        e1 = commEvent();
+        chk(mcn_event_record(e0, _commStream), "event record");
+    }
     chk(mcn_comm_group_begin(), "group begin");
     chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
     chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
     chk(mcn_comm_group_end(), "group end");
+    if (_commTiming) {
+        chk(mcn_event_record(e1, _commStream), "event record");
+        _commSpans.push_back({1, e0, e1, 2 * countPerRank});
+    }
     logComm(1, 0, countPerRank);
     logComm(1, 0, countPerRank);
 }
@@ -2476,10 +2518,12 @@ void ConvNet::fprop(int miniIdx, PassType pt) {  // convnet.cu:229-233
 }
 
 void ConvNet::bprop(PassType pt) {  // convnet.cu:206-211
+#ifdef MCN_TEST_HOOKS
     {
         std::lock_guard<std::mutex> lk(_failMutex);
         _failArmed = !_failAt.empty();
     }
+#endif
     // the fused tail is planned for full minibatches (the bias scale eps / numCases is part of the plan)
     _fusedTailNow = _fusedTailOk && pt == PASS_TRAIN && _numCases == _allocatedCases && !_profiling;
     if (_phases) profBegin("phase.backward_data_chain");
@@ -2662,7 +2706,17 @@ void ConvNet::flushBuckets(bool force) {
         if (tickMain) awaitTick(tickMain, _tickFlag);
         if (tickSide) awaitTick(tickSide, _tickFlagSide);
         const auto t0 = std::chrono::steady_clock::now();
+        void *e0 = nullptr, *e1 = nullptr;
+        if (_commTiming) {
+            e0 = commEvent();
+            e1 = commEvent();
+            chk(mcn_event_record(e0, _commStream), "event record");
+        }
         chk(mcn_allreduce_sum(_comm, buf, count, _commStream), "all-reduce");
+        if (_commTiming) {
+            chk(mcn_event_record(e1, _commStream), "event record");
+            _commSpans.push_back({0, e0, e1, count});
+        }
         logComm(0, (size_t)(buf - _gradArena.p), count);
         _rcclCallNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         _rcclCalls++;

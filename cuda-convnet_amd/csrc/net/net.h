@@ -732,8 +732,11 @@ class ConvNet {
     // (mcn_sgd_plan_build_fused); bit-identical to the separate launches.  fusedTailNow: this pass takes that path.
     bool fusedTailNow() const { return _fusedTailNow; }
     void flushBiasSums(int which = -1);  // -1: the calling thread's batch
+#ifdef MCN_TEST_HOOKS
     void failNextBackwardAt(const std::string& layer) { std::lock_guard<std::mutex> lk(_failMutex); _failAt = layer; }  // (any thread)
     bool _failArmed = false;
+#endif
+    void commInfo(int& numRanks, int& version, int& isRccl);
     void earlyUpdate();
     void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
     void finishSideWork(bool deferHostWait = false);   // end of backward: place the remaining work, then join
@@ -839,6 +842,14 @@ class ConvNet {
     bool _exchangeWorkPending = false;
     void* _evJoinComm = nullptr;
     long _rcclCallNs = 0, _rcclCalls = 0;  // exchange thread only (MCN_DEBUG_TIMES)
+    // startSteps(profile = 3): every collective bracketed by two events on the exchange stream (bench.py `rccl`)
+    bool _commTiming = false;
+    struct CommSpan { int kind; void* e0; void* e1; size_t count; };
+    std::vector<CommSpan> _commSpans;     // exchange thread appends, the worker thread reads after joining it
+    std::vector<void*> _commEventPool;
+    size_t _commEventsUsed = 0;
+    void* commEvent();
+    void commCollect(std::map<std::string, ProfEntry>& into);
     std::vector<std::pair<std::function<void()>, int>> _deferred;
     std::vector<std::function<void()>> _late;
     void runLateWork();
@@ -895,8 +906,10 @@ class ConvNet {
     int _sgdFusedCount = 0, _sgdFusedBlocks = 0;
     bool _fusedTailOk = false, _fusedTailNow = false;
     std::vector<BiasSum> _biasBatch[2];  // queued by closures on the main [0] / side [1] submitting thread
+#ifdef MCN_TEST_HOOKS
     std::string _failAt;   // failNextBackwardAt
     std::mutex _failMutex;
+#endif
     bool _failed = false;  // a data-parallel replica that lost a step: its peers wait in a collective it will never join
     void resetAfterError();
     struct ProfSpan { int label; void* e0; void* e1; size_t launches0; };

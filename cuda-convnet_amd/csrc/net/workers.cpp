@@ -118,6 +118,7 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
     zeroCosts();
     _profiling = profile == 1;
     _phases = profile == 2;
+    _commTiming = profile == 3 && dataParallel();  // steps as in a normal run, every collective bracketed by events on the exchange stream
     const int nm = _dp->numMinibatches();
     long cases = 0;
     joinGradWork();  // (nothing of an earlier work item on the side thread: its accounting starts at zero)
@@ -129,7 +130,7 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
     _sideLaunchNs = _sideLaunches = _sidePollNs = _sideWorkNs = 0;
     try {
         for (int s = 0; s < numSteps; s++) {
-            if (!test && !profile) {
+            if (!test && (!profile || profile == 3)) {
                 trainStep(s % nm);
                 cases += _numCases;
                 continue;
@@ -147,7 +148,12 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
             }
         }
         const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (profile) profCollect(res.profile);
+        if (profile == 1 || profile == 2) profCollect(res.profile);
+        if (_commTiming) {
+            sync();
+            _commSub.wait(_commSub.pushed());
+            commCollect(res.profile);
+        }
         // host-side submission time of the whole loop (launch-bound when it approaches the wall time)
         res.profile["host.enqueue"].count = numSteps;
         res.profile["host.enqueue"].ms = enq;
@@ -169,10 +175,10 @@ void ConvNet::runSteps(int numSteps, bool test, int profile) {
         put("host.side.polling_fork_ticks", _sidePollNs.load() * 1e-6, numSteps);
         put("host.side.closures_total", _sideWorkNs.load() * 1e-6, numSteps);
     } catch (...) {
-        _profiling = _phases = false;
+        _profiling = _phases = _commTiming = false;
         throw;
     }
-    _profiling = _phases = false;
+    _profiling = _phases = _commTiming = false;
     readCosts(res.cost, cases);
     res.type = WorkResult::BATCH_DONE;
     _results.enqueue(std::move(res));

@@ -570,13 +570,16 @@ int mcn_sgd_plan_build_fused(const mcn_sgd_item* items, const mcn_sgd_partials* 
 
 /* ---- data-parallel exchange (no counterpart in the reference, which is single-GPU: convnet.py:52-53).
  * RCCL is loaded lazily; one communicator per process (one process per GPU).
- * With MCN_COMM=shm in the environment of the rank that calls mcn_comm_unique_id, the id names a POSIX shared-memory
- * segment instead and the communicator stages every collective through it (fixed rank-order sums): a rehearsal
- * transport for ranks that share ONE GPU, where RCCL refuses the second rank.  Same entry points, same results on
- * every rank; not a production path. */
+ * TEST BUILD ONLY (libmiconvnet_hooks.so, -DMCN_TEST_HOOKS; the product library refuses it): with MCN_COMM=shm in the
+ * environment of the rank that calls mcn_comm_unique_id, the id names a POSIX shared-memory segment instead and the
+ * communicator stages every collective through it (fixed rank-order sums, queued on the stream like RCCL's): a rehearsal
+ * transport for ranks that share ONE GPU, where RCCL refuses the second rank.  Same entry points, same results on every rank. */
 int mcn_comm_unique_id(char idBytes[128]);
 int mcn_comm_init(void** comm, int numRanks, int rank, const char idBytes[128]);
 int mcn_comm_destroy(void* comm);
+/* the ranks the communicator itself counts (ncclCommCount), RCCL's version code (ncclGetVersion), isRccl = 0 for the
+ * rehearsal transport */
+int mcn_comm_info(void* comm, int* numRanks, int* version, int* isRccl);
 int mcn_allreduce_sum(void* comm, float* buf, size_t count, void* stream);
 int mcn_allgather(void* comm, const float* send, float* recv, size_t countPerRank, void* stream);
 /* collectives issued between begin and end are fused into one launch (ncclGroupStart / ncclGroupEnd) */

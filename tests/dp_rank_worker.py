@@ -26,11 +26,12 @@ def main():
     dp, L = preset(name, mb * world * steps, minibatch=mb * world)   # the same seeds as the single-GPU run at minibatch 128*world
     data = shard_for_rank(dp.get_next_batch()[2], rank, world, mb)
     group = Group(rank, world, token=token)
-    lib = import_native()
+    lib = import_native(hooks=True)  # the test build: the product binaries do not contain the rehearsal communicator
     lib.initModel(L, mb, 0)
     try:
         uid = group.broadcast(lib.commUniqueId() if rank == 0 else None)
         lib.initDataParallel(rank, world, uid)
+        assert lib.commInfo() == (world, 0, 0), lib.commInfo()  # the rehearsal transport counts every rank, and says it is not RCCL
         group.barrier()
         lib.startBatch(data, 0)
         costs, num_cases = lib.finishBatch()

@@ -42,8 +42,8 @@ def preset(name, cases, minibatch=128):
 class Native:
     """One model per process (pyconvnet.cu:45); always destroyed on exit."""
 
-    def __init__(self, layers, minibatch=128):
-        self.lib = import_native()
+    def __init__(self, layers, minibatch=128, hooks=False):
+        self.lib = import_native(hooks=hooks)
         self.lib.initModel(layers, minibatch, 0)
 
     def __enter__(self):
@@ -476,7 +476,7 @@ def test_a_failed_step_leaves_a_usable_model(name, layer):
     model initialised with the state it holds -- same costs, same weights, bit for bit."""
     dp, L = preset(name, 256)
     data = dp.get_next_batch()[2]
-    with Native(L) as lib:
+    with Native(L, hooks=True) as lib:  # failNextBackwardAt exists in the test build only
         for _ in range(6 if name == 'cifar10' else 1):  # (cifar10: until some cases are classified correctly, see below)
             lib.startBatch(data, 0)
             lib.finishBatch()
@@ -514,6 +514,22 @@ def test_a_failed_step_leaves_a_usable_model(name, layer):
                 assert np.array_equal(a, b), (la['name'], key)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), (la['name'], key)
+
+
+def test_product_binaries_hold_no_test_hooks():
+    """The shared-memory rehearsal communicator and failNextBackwardAt live in libmiconvnet_hooks.so / _ConvNetHooks only."""
+    lib = import_native()
+    assert not hasattr(lib, 'failNextBackwardAt')
+    assert hasattr(import_native(hooks=True), 'failNextBackwardAt')
+    from cuda_convnet_amd import capi
+    blob = open(capi.LIB_PATH, 'rb').read()
+    assert b'MCNSHM' not in blob and b'shm_open' not in blob
+    os.environ['MCN_COMM'] = 'shm'
+    try:
+        with pytest.raises(RuntimeError, match='only in the test build'):
+            lib.commUniqueId()
+    finally:
+        del os.environ['MCN_COMM']
 
 
 def test_errors_are_exceptions_not_exits():
