@@ -396,6 +396,7 @@ struct ShmComm {
     float* bounce = nullptr;  // page-locked, slotBytes
     char name[96] = {0};
     std::atomic<int> failed{0};  // a barrier inside a host function timed out: reported by the next call
+    float* stage = nullptr;      // page-locked, slotBytes: this rank's contribution on its way to the segment
 };
 static const char kShmTag[] = "MCNSHM:";
 static const size_t kShmSlotBytes = 8u << 20;
@@ -475,8 +476,14 @@ static int shm_init(McnComm* mc, int numRanks, int rank, const char* name) {
         usleep(1000);
     }
     if (rank == 0) shm_unlink(c->name);  // everyone holds a mapping: the name can go
+    // The device only ever copies to and from PAGE-LOCKED buffers of this process (`stage` out, `bounce` in): a copy that
+    // touches pageable memory -- the shared segment cannot be registered -- is staged by the runtime when the call is MADE,
+    // not when the stream reaches it, and the H2D of a collective would read the slots before the peers have filled them.
+    // The segment itself is read and written by the host functions only.
     int rc = mcn_check_hip(hipHostMalloc((void**)&c->bounce, c->slotBytes, hipHostMallocDefault), "hipHostMalloc");
+    if (!rc) rc = mcn_check_hip(hipHostMalloc((void**)&c->stage, c->slotBytes, hipHostMallocDefault), "hipHostMalloc");
     if (rc) {
+        if (c->bounce) (void)hipHostFree(c->bounce);
         munmap(m, c->mapBytes);
         delete c;
         return rc;
@@ -495,20 +502,19 @@ struct ShmStep {
 static void shm_host_reduce(void* arg) {
     ShmStep* st = (ShmStep*)arg;
     ShmComm* c = st->c;
+    memcpy(c->slots + (size_t)c->rank * c->slotBytes, c->stage, st->n * 4);
     if (shm_barrier(c, "collective (shm)")) c->failed.store(1);  // every rank's slot is filled
-    if (!st->gather) {
+    if (st->gather) {
+        for (int r = 0; r < c->numRanks; r++) memcpy(c->bounce + (size_t)r * st->n, c->slots + (size_t)r * c->slotBytes, st->n * 4);
+    } else {
         const float* s0 = (const float*)c->slots;
         for (size_t i = 0; i < st->n; i++) c->bounce[i] = s0[i];
         for (int r = 1; r < c->numRanks; r++) {
             const float* sr = (const float*)(c->slots + (size_t)r * c->slotBytes);
             for (size_t i = 0; i < st->n; i++) c->bounce[i] += sr[i];
         }
-        if (shm_barrier(c, "collective (shm)")) c->failed.store(1);  // every rank has read the slots: they may be refilled
     }
-}
-static void shm_host_release(void* arg) {
-    ShmStep* st = (ShmStep*)arg;
-    if (st->gather && shm_barrier(st->c, "collective (shm)")) st->c->failed.store(1);  // every rank has copied the slots out
+    if (shm_barrier(c, "collective (shm)")) c->failed.store(1);  // every rank has read the slots: they may be refilled
     delete st;
 }
 
@@ -519,15 +525,10 @@ static int shm_exchange(ShmComm* c, const float* send, float* recv, size_t n, bo
         return MCN_ERCCL;
     }
     ShmStep* st = new ShmStep{c, n, gather, true};
-    int rc = mcn_check_hip(hipMemcpyAsync(c->slots + (size_t)c->rank * c->slotBytes, send, n * 4, hipMemcpyDeviceToHost, s), what);
+    int rc = mcn_check_hip(hipMemcpyAsync(c->stage, send, n * 4, hipMemcpyDeviceToHost, s), what);
     if (!rc) rc = mcn_check_hip(hipLaunchHostFunc(s, shm_host_reduce, st), what);
-    if (gather) {
-        for (int r = 0; r < c->numRanks && !rc; r++)
-            rc = mcn_check_hip(hipMemcpyAsync(recv + (size_t)r * n, c->slots + (size_t)r * c->slotBytes, n * 4, hipMemcpyHostToDevice, s), what);
-    } else if (!rc) {
-        rc = mcn_check_hip(hipMemcpyAsync(recv, c->bounce, n * 4, hipMemcpyHostToDevice, s), what);
-    }
-    if (!rc) rc = mcn_check_hip(hipLaunchHostFunc(s, shm_host_release, st), what);
+    else delete st;
+    if (!rc) rc = mcn_check_hip(hipMemcpyAsync(recv, c->bounce, (gather ? (size_t)c->numRanks : 1) * n * 4, hipMemcpyHostToDevice, s), what);
     return rc;
 }
 #endif  // MCN_TEST_HOOKS
@@ -593,6 +594,7 @@ MCN_API int mcn_comm_destroy(void* comm) {
     if (mc->shm) {
         (void)hipDeviceSynchronize();  // (host functions of queued collectives still hold the segment)
         if (mc->shm->bounce) (void)hipHostFree(mc->shm->bounce);
+        if (mc->shm->stage) (void)hipHostFree(mc->shm->stage);
         munmap(mc->shm->hdr, mc->shm->mapBytes);
         delete mc->shm;
     } else
@@ -626,7 +628,7 @@ MCN_API int mcn_allgather(void* comm, const float* send, float* recv, size_t cou
     MCN_REQUIRE(mc && send && recv, "mcn_allgather: communicator not initialised");
 #ifdef MCN_TEST_HOOKS
     if (mc->shm) {
-        MCN_REQUIRE(countPerRank * 4 <= mc->shm->slotBytes, "mcn_allgather: more than %zu bytes per rank (shared-memory communicator)",
+        MCN_REQUIRE(countPerRank * 4 * mc->shm->numRanks <= mc->shm->slotBytes, "mcn_allgather: more than %zu bytes in all (shared-memory communicator)",
                     mc->shm->slotBytes);
         return shm_exchange(mc->shm, send, recv, countPerRank, true, (hipStream_t)stream, "allgather (shm)");
     }

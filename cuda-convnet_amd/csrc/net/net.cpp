@@ -338,20 +338,26 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
     // last weight layer of the pass, which has nothing left to hide behind and is split over both streams
     const bool last = _net->lastWeightLayerOfPass(this);
     if (last && pt == PASS_TRAIN) _net->earlyUpdate();  // (queued ahead of this layer's own pieces, see there)
-    _net->deferSideWork([this, v, pt, last] {
-        const bool inWgrad = _biasInWgrad && pt == PASS_TRAIN && _net->fusedTailNow();  // (comes with the weight gradient below)
-        if (_biases->eps() > 0 && !inWgrad) {
-            if (_net->biasBatching()) {  // a row sum like every other layer's: all of them in one launch at the end of the pass
-                int rows, cols;
-                biasSumShape(_net->numCases(), rows, cols);
-                _net->queueBiasSum(_biases->gradBuf(), v, rows, cols, gradScale(_biases->eps(), pt), _biasParts.p);
-            } else {
-                ProfScope ps(_net, _name, "bpropBiases");
-                bpropBiases(v, pt);
+    // the bias gradient: a row sum queued for the pass's one batched launch -- unless the weight-gradient launch below
+    // delivers it (conv, strip form).  The batch goes out with the LAST layer of the pass that adds to it, so that a last
+    // layer without a bias piece of its own (DeepID's conv1) leaves nothing for the side stream to do at the very end.
+    const bool biasHere = _biases->eps() > 0 && !(_biasInWgrad && pt == PASS_TRAIN && _net->fusedTailNow());
+    const bool flushHere = _net->biasBatching() && _net->flushesBiasBatch(this, last);
+    if (biasHere || flushHere) {
+        _net->deferSideWork([this, v, pt, biasHere, flushHere] {
+            if (biasHere) {
+                if (_net->biasBatching()) {  // a row sum like every other layer's: all of them in one launch
+                    int rows, cols;
+                    biasSumShape(_net->numCases(), rows, cols);
+                    _net->queueBiasSum(_biases->gradBuf(), v, rows, cols, gradScale(_biases->eps(), pt), _biasParts.p);
+                } else {
+                    ProfScope ps(_net, _name, "bpropBiases");
+                    bpropBiases(v, pt);
+                }
             }
-        }
-        if (last) _net->flushBiasSums();
-    }, 1, true);
+            if (flushHere) _net->flushBiasSums();
+        }, 1, true);
+    }
     _net->deferSideWork([this, v, pt] {
         for (int i = 0; i < (int)_weights.size(); i++) {
             if (_weights[i]->eps() > 0) {
@@ -361,7 +367,7 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
             }
         }
         if (_net->dataParallel() && pt == PASS_TRAIN) _net->gradReady(this);
-    }, 1, last);
+    }, (biasHere || flushHere || last) ? 1 : 2, last);  // (a layer without a bias piece still goes to the side stream at once)
 }
 
 void WeightLayer::updateWeights() {
@@ -2128,6 +2134,15 @@ void ConvNet::flushBiasSums(int which) {
         }
     }
     b.clear();
+}
+
+// wl is the last layer of this pass that queues a bias row sum (known from the second pass on; until then `last` decides)
+bool ConvNet::flushesBiasBatch(WeightLayer* wl, bool last) {
+    if (_passOrder.empty() || _passNow.size() > _passOrder.size() || !std::equal(_passNow.begin(), _passNow.end(), _passOrder.begin())) return last;
+    WeightLayer* lastQueuer = nullptr;
+    for (WeightLayer* l : _passOrder)
+        if (l->queuesBiasSum(_fusedTailNow)) lastQueuer = l;
+    return lastQueuer ? lastQueuer == wl : last;
 }
 
 bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {

@@ -197,6 +197,7 @@ class WeightLayer : public Layer {
     void weightsUpdated() override;
     void resetUpdateCounters() override;
     bool sharesWeights() const;  // holds a matrix that another Weights object owns
+    bool queuesBiasSum(bool fusedTail) const { return _biases->eps() > 0 && !(_biasInWgrad && fusedTail); }
     void copyToCPU() override;
     void copyToGPU() override;
     void checkGradients(std::vector<GradCheckResult>& out, long maxElems, bool central) override;
@@ -724,6 +725,7 @@ class ConvNet {
     // between the side stream and the main stream.
     void deferSideWork(std::function<void()> fn, int units, bool hold = false);  // flushed to the side stream once _sideUnits are waiting (hold: not by this call)
     bool lastWeightLayerOfPass(WeightLayer* wl);
+    bool flushesBiasBatch(WeightLayer* wl, bool last);
     // bias gradients of a backward pass, handed to ONE mcn_add_sum_multi by the last weight layer's bias piece (single GPU)
     bool biasBatching() const;
     void queueBiasSum(float* tgt, const float* mat, int rows, int cols, float scaleSum, float* partsOut);
