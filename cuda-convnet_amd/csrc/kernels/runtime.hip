@@ -12,6 +12,7 @@
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 
 static thread_local char g_err[512] = "";
@@ -130,6 +131,18 @@ MCN_API int mcn_tile_minibatches(const float* src, float* dst, int rows, size_t 
 MCN_API int mcn_stream_create(void** stream) {
     hipStream_t s;
     int rc = mcn_check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    *stream = (void*)s;
+    return rc;
+}
+// A stream on a hardware queue of its own: the runtime hands out its queues per priority level, and streams of one level
+// share them once there are more streams than queues (measured with rocprofv3 on MI355X / ROCm 7.2: a fifth normal stream
+// landed on the first one's queue, and the exchange stream's collectives ran in line with the main stream's kernels).
+MCN_API int mcn_stream_create_priority(void** stream, int level) {  // level < 0: lowest, > 0: highest, 0: normal
+    int least = 0, greatest = 0;
+    int rc = mcn_check_hip(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+    if (rc) return rc;
+    hipStream_t s;
+    rc = mcn_check_hip(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, level < 0 ? least : level > 0 ? greatest : 0), "hipStreamCreateWithPriority");
     *stream = (void*)s;
     return rc;
 }
@@ -397,6 +410,12 @@ struct ShmComm {
     char name[96] = {0};
     std::atomic<int> failed{0};  // a barrier inside a host function timed out: reported by the next call
     float* stage = nullptr;      // page-locked, slotBytes: this rank's contribution on its way to the segment
+    // collectives of one communicator are ordered even when they are issued on different streams (as RCCL orders them):
+    // each one waits for the previous one's completion event before it touches the staging buffers
+    hipEvent_t lastDone = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool any = false;
+    std::mutex order;
 };
 static const char kShmTag[] = "MCNSHM:";
 static const size_t kShmSlotBytes = 8u << 20;
@@ -524,11 +543,17 @@ static int shm_exchange(ShmComm* c, const float* send, float* recv, size_t n, bo
         mcn_set_error("%s: an earlier collective timed out waiting for a peer (shared-memory communicator)", what);
         return MCN_ERCCL;
     }
+    std::lock_guard<std::mutex> lk(c->order);
+    if (!c->lastDone && mcn_check_hip(hipEventCreateWithFlags(&c->lastDone, hipEventDisableTiming), what)) return MCN_EHIP;
+    if (c->any && c->lastStream != s && mcn_check_hip(hipStreamWaitEvent(s, c->lastDone, 0), what)) return MCN_EHIP;
     ShmStep* st = new ShmStep{c, n, gather, true};
     int rc = mcn_check_hip(hipMemcpyAsync(c->stage, send, n * 4, hipMemcpyDeviceToHost, s), what);
     if (!rc) rc = mcn_check_hip(hipLaunchHostFunc(s, shm_host_reduce, st), what);
     else delete st;
     if (!rc) rc = mcn_check_hip(hipMemcpyAsync(recv, c->bounce, (gather ? (size_t)c->numRanks : 1) * n * 4, hipMemcpyHostToDevice, s), what);
+    if (!rc) rc = mcn_check_hip(hipEventRecord(c->lastDone, s), what);
+    c->lastStream = s;
+    c->any = true;
     return rc;
 }
 #endif  // MCN_TEST_HOOKS
@@ -595,6 +620,7 @@ MCN_API int mcn_comm_destroy(void* comm) {
         (void)hipDeviceSynchronize();  // (host functions of queued collectives still hold the segment)
         if (mc->shm->bounce) (void)hipHostFree(mc->shm->bounce);
         if (mc->shm->stage) (void)hipHostFree(mc->shm->stage);
+        if (mc->shm->lastDone) (void)hipEventDestroy(mc->shm->lastDone);
         munmap(mc->shm->hdr, mc->shm->mapBytes);
         delete mc->shm;
     } else

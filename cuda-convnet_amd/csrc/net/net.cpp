@@ -1194,12 +1194,15 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
     float *idens = _inputs[0], *data = _inputs[1];
     _readyOnExchange = gather && _net->exchangeThreadUsable();
     if (_readyOnExchange) {
-        _readyTicket = _net->forkExchangeWork([this, idens, data, D, n, h, G] {
+        const int cgSeq = _net->commGatesUsable() ? _net->nextCommGateSeq() : 0;
+        _readyCommGateSeq = cgSeq;
+        _readyTicket = _net->forkExchangeWork([this, idens, data, D, n, h, G, cgSeq] {
             void* st = _net->stream();  // the exchange stream: statistics, gather, margin search and cost in stream order
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, st), "l2sn pair stats");
             _net->gatherPairsHere(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
             chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, nullptr, dCost, _gathered.p, _gathered.p + _extCount, _extCount, st), "l2sn cost");
-            chk(mcn_event_record(_evReady, st), "event record");
+            if (cgSeq) _net->signalCommGate(cgSeq);
+            else chk(mcn_event_record(_evReady, st), "event record");
         });
         return;
     }
@@ -1250,6 +1253,9 @@ void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  //
         // a gate may be queued before its signal has been launched: no hand-shake with the side thread, no barrier packet
         _net->awaitGate(_readyGateSeq);
         _readyGateSeq = 0;
+    } else if (_readyOnExchange && _readyCommGateSeq && t_stream == 0) {
+        _net->awaitCommGate(_readyCommGateSeq);
+        _readyCommGateSeq = 0;
     } else {
         if (_readyOnExchange) _net->waitExchangeSubmitted(_readyTicket);  // that thread has recorded _evReady
         else _net->waitSideSubmitted(_readyTicket);
@@ -1299,7 +1305,10 @@ void L2regCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  /
 // ============================================================================ Uploader
 
 void Uploader::start(int deviceID) {
-    chk(mcn_stream_create(&_stream), "copy stream");
+    // lowest priority, i.e. out of the normal level's pool of hardware queues: with a fifth normal stream the runtime doubles
+    // up (rocprofv3 on MI355X / ROCm 7.2: the exchange stream's collectives ran on the main stream's queue, in line with its kernels)
+    static const bool plain = getenv("MCN_COPY_STREAM_NORMAL") != nullptr;  // (A/B switch)
+    chk(plain ? mcn_stream_create(&_stream) : mcn_stream_create_priority(&_stream, -1), "copy stream");
     for (int k = 0; k < 2; k++) {
         chk(mcn_host_alloc(&_chunk[k], kChunkBytes), "pinned staging chunk");
         chk(mcn_event_create_sync(&_chunkEv[k]), "event");
@@ -1629,6 +1638,8 @@ ConvNet::~ConvNet() {
     for (void* e : _forkEvents) mcn_event_destroy(e);
     if (_gate) mcn_gate_free(_gate);
     if (_forkGate) mcn_gate_free(_forkGate);
+    for (int* g : {_commGate, _mainToComm, _sideToComm})
+        if (g) mcn_gate_free(g);
     if (_tickFlag) mcn_tick_free(_tickFlag);
     if (_tickFlagSide) mcn_tick_free(_tickFlagSide);
     if (_evJoin) mcn_event_destroy(_evJoin);
@@ -1761,6 +1772,11 @@ void ConvNet::resetAfterError() {
     // a gate the failed pass queued on the main stream may wait for a signal that will never be sent (the closure that
     // carried it was dropped): release it from the side stream, which is idle now
     if (_gate && _gateOk) mcn_stream_signal(_gate, _gateSeq, _gradStream);
+    if (_commGateOk) {  // (best effort; a gate nobody can release any more ends by its own timeout)
+        mcn_stream_signal(_sideToComm, _sideToCommSeq, _gradStream);
+        mcn_stream_signal(_mainToComm, _mainToCommSeq, _gradStream);
+        mcn_stream_signal(_commGate, _commGateSeq, _gradStream);
+    }
     _deferred.clear();
     _deferredUnits = 0;
     _late.clear();
@@ -1803,7 +1819,8 @@ void ConvNet::resetAfterError() {
     mcn_device_sync();  // (a sticky device error shows up in the next call's status)
     if (_gate && _gateOk) {  // a gate that did run into its timeout has been reported with this error: start clean
         mcn_memset(_gate + 1, 0, sizeof(int), _stream);
-        if (_forkGate) mcn_memset(_forkGate + 1, 0, sizeof(int), _stream);
+        for (int* g : {_forkGate, _commGate, _mainToComm, _sideToComm})
+            if (g) mcn_memset(g + 1, 0, sizeof(int), _stream);
         mcn_stream_sync(_stream);
     }
 }
@@ -1978,7 +1995,30 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
     dropStepGraphs();
     if (_dpOn) {
         chk(mcn_comm_init(&_comm, world, rank, id128), "comm init");
+        // The exchange stream would like a hardware queue of its own; the runtime decides.  Measured with rocprofv3 on MI355X /
+        // ROCm 7.2: streams are doubled up on the hardware queues long before GPU_MAX_HW_QUEUES (with the upload stream at the
+        // lowest priority the exchange stream lands on the SIDE stream's queue, otherwise on the main stream's), and forcing a
+        // queue of its own -- more streams until one tests independent, or a stream of the highest priority -- over-subscribes
+        // the queues: every kernel next to its work ran 2-3 times longer (forced data-parallel step 0.33 -> 0.75 ms).  So: one
+        // normal stream, and the gate self-test decides whether it may be gated (independent queue) or keeps its events.
+        int nr = 0, ver = 0, isRccl = 0;
+        chk(mcn_comm_info(_comm, &nr, &ver, &isRccl), "comm info");
+        // Ranks of the rehearsal transport (test build) SHARE one GPU and wait for each other inside their collectives: a
+        // gate of one rank would spin on the device its peer needs to get there.  Spinning is for ranks that own their GPU.
+        if (!isRccl && world > 1) _gateOk = _forkGateOk = false;
         chk(mcn_stream_create(&_commStream), "comm stream");
+        if (_gateOk && _gradStream && getenv("MCN_NO_COMM_GATES") == nullptr) {
+            chk(mcn_gate_alloc(&_commGate), "gate");
+            chk(mcn_gate_alloc(&_mainToComm), "gate");
+            chk(mcn_gate_alloc(&_sideToComm), "gate");
+            int a = 0, b = 0, c = 0;
+            chk(mcn_gate_selftest(_commGate, _stream, _commStream, &a), "gate self-test");
+            if (a) chk(mcn_gate_selftest(_mainToComm, _commStream, _stream, &b), "gate self-test");
+            if (b) chk(mcn_gate_selftest(_sideToComm, _commStream, _gradStream, &c), "gate self-test");
+            _commGateOk = a && b && c;
+            if (getenv("MCN_DEBUG_TIMES"))
+                fprintf(stderr, "[mcn] exchange stream: %s\n", _commGateOk ? "a hardware queue of its own (gates on)" : "shares a hardware queue (events)");
+        }
         chk(mcn_event_create_sync(&_evGrad), "event");
         chk(mcn_event_create_sync(&_evGrad2), "event");
         chk(mcn_event_create_sync(&_evGather), "event");
@@ -2001,7 +2041,8 @@ void ConvNet::commInfo(int& numRanks, int& version, int& isRccl) {
 void ConvNet::sync() {
     joinGradWork();
     chk(mcn_stream_sync(_stream), "sync");
-    for (int* g : {_gateOk ? _gate : nullptr, _forkGateOk ? _forkGate : nullptr}) {
+    for (int* g : {_gateOk ? _gate : nullptr, _forkGateOk ? _forkGate : nullptr, _commGateOk ? _commGate : nullptr,
+                   _commGateOk ? _mainToComm : nullptr, _commGateOk ? _sideToComm : nullptr}) {
         if (!g) continue;
         int timedOut = 0;
         chk(mcn_gate_timed_out(g, &timedOut, _stream), "gate state");
@@ -2011,9 +2052,15 @@ void ConvNet::sync() {
 
 // ---- side-stream submission -----------------------------------------------------------------
 static constexpr int kGateTimeoutMs = 5000;
-// (not for data-parallel replicas: RCCL brings streams of its own, and streams that end up sharing a hardware queue would turn
-// a gate into its timeout; their joins stay events)
-bool ConvNet::gatesUsable() const { return _gateOk && !_dpOn && !_capturing && !g_noHostWait && !_profiling; }
+// (the self-tests at start-up cover the pairs of streams that gate each other: main / side here, main / exchange in initComm)
+bool ConvNet::gatesUsable() const { return _gateOk && !_capturing && !g_noHostWait && !_profiling; }
+bool ConvNet::g_noHostWaitFlag() { return g_noHostWait; }
+void ConvNet::signalCommGate(int seq) { chk(mcn_stream_signal(_commGate, seq, _commStream), "stream signal (exchange)"); }
+void ConvNet::awaitCommGate(int seq) {
+    const auto t0 = std::chrono::steady_clock::now();
+    chk(mcn_stream_gate(_commGate, seq, kGateTimeoutMs, _stream), "stream gate (exchange)");
+    g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 void ConvNet::signalGate(int seq) { chk(mcn_stream_signal(_gate, seq, stream()), "stream signal"); }
 void ConvNet::awaitGate(int seq) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -2256,7 +2303,7 @@ void ConvNet::flushSideWork(size_t count) {
         tick = ++_tickSeq;
         static const bool ownKernel = getenv("MCN_TICK_KERNEL") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        gateFork = _forkGateOk && !ownKernel && !_dpOn;
+        gateFork = _forkGateOk && !ownKernel;
         if (ownKernel) chk(mcn_stream_tick(_tickFlag, tick, _stream), "stream tick");
         else chk(mcn_arm_tick_gate(_tickFlag, gateFork ? _forkGate : nullptr, tick, _stream), "arm tick");
         g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -2680,6 +2727,31 @@ void ConvNet::flushBuckets(bool force) {
     if (end == _sentUpTo) return;
     if (!force && end - _sentUpTo < _bucketFloats) return;
     if (t_stream == 1) flushBiasSums();  // (the bias gradients of this bucket's layers, queued by this thread, on this stream)
+    // The last bucket of a step -- the forced flush after the join, on the thread that feeds the main stream, which by then
+    // follows everything either stream wrote -- is exchanged IN LINE on the main stream: no hop to the exchange thread, no
+    // cross-queue wait there and back (two of the 10-15 us waits at the very end of every step; its payload is the last
+    // layers' few kilobytes).  The earlier collectives have all been issued by then, so the order of calls is the same on
+    // every rank.
+    static const bool inlineLast = getenv("MCN_NO_INLINE_BUCKET") == nullptr;
+    if (force && inlineLast && t_stream == 0 && !_gradPending && !_capturing) {
+        _commSub.wait(_commSub.pushed());
+        float* lbuf = _gradArena.p + _sentUpTo;
+        const size_t lcount = end - _sentUpTo;
+        void *e0 = nullptr, *e1 = nullptr;
+        if (_commTiming) {
+            e0 = commEvent();
+            e1 = commEvent();
+            chk(mcn_event_record(e0, _stream), "event record");
+        }
+        chk(mcn_allreduce_sum(_comm, lbuf, lcount, _stream), "all-reduce (last bucket, main stream)");
+        if (_commTiming) {
+            chk(mcn_event_record(e1, _stream), "event record");
+            _commSpans.push_back({0, e0, e1, lcount});
+        }
+        logComm(0, _sentUpTo, lcount);
+        _sentUpTo = end;
+        return;
+    }
     // the exchange waits for the stream(s) that hold the kernels writing this bucket (a record + wait pair costs ~16 us
     // of host time, so only where needed; force: whatever is left, written by either stream)
     bool onMain = force, onSide = force && _gradPending;
@@ -2693,10 +2765,16 @@ void ConvNet::flushBuckets(bool force) {
     void* evSide = nullptr;
     // (a stream's ticks must be queued in increasing order: only the thread that feeds a stream ticks it, anyone else
     // records an event -- the side thread sends side-stream buckets, the main thread the forced rest, so that is rare)
-    int tickMain = 0, tickSide = 0;
+    int tickMain = 0, tickSide = 0, gateMain = 0, gateSide = 0;
     const bool ticks = _commTicks && !_capturing && !g_noHostWait;
+    // (a stream is signalled by the thread that feeds it, so that the numbers of a word increase in stream order; the rare
+    // case of the other thread -- the main thread's forced flush of what the side stream wrote -- keeps its event)
+    const bool cg = commGatesUsable();
     if (onMain) {
-        if (ticks && t_stream == 0) {
+        if (cg && t_stream == 0) {
+            gateMain = ++_mainToCommSeq;
+            chk(mcn_stream_signal(_mainToComm, gateMain, _stream), "stream signal");
+        } else if (ticks && t_stream == 0) {
             tickMain = ++_tickSeq;
             chk(mcn_stream_tick(_tickFlag, tickMain, _stream), "stream tick");
         } else {
@@ -2705,7 +2783,10 @@ void ConvNet::flushBuckets(bool force) {
         }
     }
     if (onSide) {
-        if (ticks && t_stream == 1) {
+        if (cg && t_stream == 1) {
+            gateSide = ++_sideToCommSeq;
+            chk(mcn_stream_signal(_sideToComm, gateSide, _gradStream), "stream signal");
+        } else if (ticks && t_stream == 1) {
             tickSide = ++_tickSeqSide;
             chk(mcn_stream_tick(_tickFlagSide, tickSide, _gradStream), "stream tick");
         } else {
@@ -2715,7 +2796,9 @@ void ConvNet::flushBuckets(bool force) {
     }
     float* buf = _gradArena.p + _sentUpTo;
     const size_t count = end - _sentUpTo;
-    _commSub.push([this, evMain, evSide, tickMain, tickSide, buf, count] {
+    _commSub.push([this, evMain, evSide, tickMain, tickSide, gateMain, gateSide, buf, count] {
+        if (gateMain) chk(mcn_stream_gate(_mainToComm, gateMain, kGateTimeoutMs, _commStream), "stream gate (bucket)");
+        if (gateSide) chk(mcn_stream_gate(_sideToComm, gateSide, kGateTimeoutMs, _commStream), "stream gate (bucket)");
         if (evMain) chk(timedStreamWait(_commStream, evMain), "wait event");
         if (evSide) chk(timedStreamWait(_commStream, evSide), "wait event");
         if (tickMain) awaitTick(tickMain, _tickFlag);
@@ -2743,9 +2826,16 @@ void ConvNet::flushBuckets(bool force) {
 void ConvNet::waitComm() {
     std::lock_guard<std::mutex> lk(_commMutex);
     if (_commPending) {
-        _commSub.wait(_commSub.pushed());  // every exchange of this step has been issued
-        chk(timedEventRecord(_evComm, _commStream), "event record");
-        chk(timedStreamWait(_stream, _evComm), "wait event");
+        if (commGatesUsable()) {  // the exchange thread signals behind its last collective; the gate is queued at once
+            const int seq = nextCommGateSeq();
+            _commSub.push([this, seq] { t_stream = 2; signalCommGate(seq); });
+            awaitCommGate(seq);
+            _commSub.wait(_commSub.pushed());  // (the segment flags below are the exchange closures' until they have run)
+        } else {
+            _commSub.wait(_commSub.pushed());  // every exchange of this step has been issued
+            chk(timedEventRecord(_evComm, _commStream), "event record");
+            chk(timedStreamWait(_stream, _evComm), "wait event");
+        }
         _commPending = false;
     }
     _sentUpTo = 0;

@@ -475,11 +475,12 @@ class L2SNCostLayer : public CostLayer {
     void* _evReady = nullptr;  // recorded after the cost launch, on whichever stream ran it
     long _readyTicket = 0;
     int _readyGateSeq = 0;  // != 0: the statistics are announced by a stream gate signal with this number, not by _evReady
+    int _readyCommGateSeq = 0;  // ... on the exchange stream (data parallel)
     bool _readyOnExchange = false;
     int _extCount = 0;
     bool _earlyGrad = false;  // this pass already sent its gradient (forward, side stream)
    public:
-    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; _readyGateSeq = 0; }
+    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; _readyGateSeq = 0; _readyCommGateSeq = 0; }
    protected:
 };
 
@@ -819,6 +820,21 @@ class ConvNet {
     int* _forkGate = nullptr;  // main stream -> side stream: the fork ticks' device word; the side thread queues a gate on the side
                                // stream instead of polling the host word (it never blocks, and neither does the main thread for it)
     bool _forkGateOk = false;
+    // data parallel: exchange stream -> main stream (all-reduced gradients, the L2-SN statistics) and the two compute
+    // streams -> exchange stream (a bucket's gradients are complete), each direction with a word and a counter of its own
+    int* _commGate = nullptr;      // signalled on the exchange stream (exchange thread), awaited on the main stream
+    int _commGateSeq = 0;
+    int* _mainToComm = nullptr;    // signalled on the main stream (main thread), awaited on the exchange stream
+    int* _sideToComm = nullptr;    // signalled on the side stream (side thread), awaited on the exchange stream
+    int _mainToCommSeq = 0, _sideToCommSeq = 0;
+    bool _commGateOk = false;
+   public:
+    bool commGatesUsable() const { return _commGateOk && !_capturing && !g_noHostWaitFlag() && !_profiling; }
+    int nextCommGateSeq() { return ++_commGateSeq; }
+    void signalCommGate(int seq);  // exchange thread, on the exchange stream
+    void awaitCommGate(int seq);   // queued on the main stream
+   private:
+    static bool g_noHostWaitFlag();
     int _gateSeq = 0;
     bool _gateOk = false;
     bool _sideWaitPending = false;

@@ -74,6 +74,10 @@ int mcn_copy2d(void* dst, size_t dpitchBytes, const void* src, size_t spitchByte
 int mcn_tile_minibatches(const float* src, float* dst, int rows, size_t numCases, int minibatch, void* stream);
 int mcn_stream_create(void** stream);
 int mcn_stream_destroy(void* stream);
+/* A stream of another priority level (level < 0 lowest, > 0 highest): the runtime hands out its hardware queues per level and
+ * streams of one level share them once there are more streams than queues, so a background stream of its own level (the
+ * upload stream) leaves the normal level's queues to the streams that must run side by side. */
+int mcn_stream_create_priority(void** stream, int level);
 int mcn_stream_sync(void* stream);
 int mcn_device_sync(void);
 int mcn_event_create(void** event);
