@@ -27,6 +27,7 @@ struct BwdDataParams {
     int uNeuron;         // >= 0: times the gradient of the neuron that produced uActs
     float uNa, uNb;
     McnTick tick;        // stored by the launch's first thread (MCN_TICK_PROLOGUE)
+    int waveCt;          // 1: the four waves of a block are four channel tiles of ONE pixel (they read the same gradient rows)
 };
 
 // A step = one (module, 16 filters) pair.  The steps a pixel needs are walked in batches of U: the loads of the
@@ -39,6 +40,11 @@ struct BwdDataParams {
 // gradient kernel would compute from `targets` in a second and third pass (layer.cu:734, :251), bit for bit.
 // UNDO: 0 off, 1 through the pool only, 2 through the pool and a relu (a run-time neuron switch per element was tried: the
 // unrolled epilogue grew to 28 k instructions and the launch lost more in instruction fetch than the fusion saved)
+// (A statically pipelined form for the long step chains of wide layers -- full batches only, one batch in flight behind explicit
+// s_waitcnt, scheduling barriers, as in k_weight_acts_wide -- was built and measured in round 3: DeepID2+ conv2 120 -> 154 us and
+// local3 115 -> 137 us alone with one wave per pixel, 86 -> 81 us with the channel-tile blocks below, and the two-stream step got
+// SLOWER either way (0.770 -> 0.800 ms): its 230 VGPRs and the deeper load queue take from the weight-gradient kernels on the
+// other queue what the chain gains.  Removed again.)
 template <int CV, int NQ, bool VECN, int U, int KS = 1, int UNDO = 0>
 __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     MCN_TICK_PROLOGUE(p);
@@ -46,15 +52,17 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const int M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int pxRaw = blockIdx.y * (4 / KS) + wave / KS, ks = wave % KS;
+    const bool wct = KS == 1 && p.waveCt;
+    const int pxRaw = wct ? (int)blockIdx.y : blockIdx.y * (4 / KS) + wave / KS, ks = wave % KS;
     const bool live = pxRaw < imgPixels;
     if (KS == 1 && !live) return;  // (with KS == 2 every wave reaches the barrier below)
     const int px = live ? pxRaw : imgPixels - 1;
     const int y = px / p.imgX, x = px % p.imgX;
     const int n0 = blockIdx.x * (64 * NQ);
     const int ctiles = (fc + 16 * CV - 1) / (16 * CV);
-    const int grp = blockIdx.z / ctiles;
-    const int c0 = (blockIdx.z % ctiles) * 16 * CV;  // channel within the group
+    const int zi = wct ? (int)blockIdx.z * 4 + wave : (int)blockIdx.z;
+    const int grp = zi / ctiles;
+    const int c0 = (zi % ctiles) * 16 * CV;  // channel within the group
 
     // modules covering this pixel (img_acts.cu:435-440)
     const int startY = y - p.pad < p.fs ? 0 : 1 + (y - p.pad - p.fs) / p.stride;
@@ -349,6 +357,7 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     p.pad = pad; p.stride = stride; p.groups = groups; p.conv = conv; p.sT = sT; p.sO = sO;
     p.uActs = nullptr; p.uMax = nullptr; p.uTarget = nullptr; p.uNeuron = -1; p.uNa = p.uNb = 0.f;
     p.tick = {nullptr, 0};
+    p.waveCt = 0;
     const int fc = C / groups, imgPixels = imgY * imgX;
     const bool vecn = (N % 4 == 0) && (((uintptr_t)hidActs | (uintptr_t)targets) % 16 == 0);
     if (undo) {
@@ -387,6 +396,13 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
         (long)divup(N, 64) * imgPixels * groups * (ct16 / 2) < 2048) {
         CV = 2; NQ = 1; ksplit = wideKs == 2 ? 2 : 4;
         grid = dim3(divup(N, 64), divup(imgPixels, 4), groups * (ct16 / 2));
+    }
+    // one wave per (pixel, channel tile) and several channel tiles: a block = the channel tiles of one pixel, so the gradient
+    // rows (the larger operand, the same for every channel tile) come from L2 once per block instead of once per wave
+    static const int waveCtEnv = getenv("MCN_IA_WAVECT") ? atoi(getenv("MCN_IA_WAVECT")) : 1;
+    if (waveCtEnv && !ksplit && (groups * divup(fc, 16 * CV)) % 4 == 0 && imgPixels <= 65535) {
+        p.waveCt = 1;
+        grid = dim3(divup(N, 64 * NQ), imgPixels, groups * divup(fc, 16 * CV) / 4);
     }
     switch (CV) {
         case 4: launch_bd1<4>(p, NQ, grid, vecn, pipelined, 0, s); break;

@@ -194,6 +194,117 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
         }
 }
 
+// Wide layers (128 filters or more, K a multiple of 32 KV: DeepID2+).  One wave owns 16 KV weight rows x 64 filters of one module
+// chunk and walks (module, 16 images) as ONE statically pipelined sequence: no split of the images or modules over the waves
+// of a block, so no LDS sum and no idle waves at the end; the four waves of a block are 2 row tiles x 2 filter tiles (each
+// operand row is asked for by two waves of the same CU).  MFMA roles are swapped against k_weight_acts -- A = gradient rows,
+// B = image rows -- so that a lane ends up with four CONSECUTIVE filters of one weight row: the epilogue (and the momentum
+// term it reads, local layers) is 16-byte accesses.  One batch of loads in flight, explicit waits (see k_img_acts CHAIN).
+template <int KV>
+__global__ __launch_bounds__(256) void k_weight_acts_wide(BwdWParams p) {
+    MCN_TICK_PROLOGUE(p);
+    constexpr int FV = 4;
+    extern __shared__ int tbl[];
+    const int fp = p.fs * p.fs, K = p.C * fp, M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
+    const int kb0 = blockIdx.y * (32 * KV);
+    for (int i = threadIdx.x; i < 32 * KV; i += 256) {
+        const int k = kb0 + i, c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
+        tbl[2 * i] = c * imgPixels + fy * p.imgX + fx;
+        tbl[2 * i + 1] = (fy << 16) | fx;
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    const int chunk = blockIdx.x;
+    const int kl = (wave & 1) * 16 * KV, kb = kb0 + kl;
+    const int f0 = blockIdx.z * 128 + (wave >> 1) * 64;
+    const bool check = p.check != 0;
+    int off[KV], yx[KV];
+#pragma unroll
+    for (int v = 0; v < KV; v++) {
+        off[v] = tbl[2 * (kl + 16 * v + j)];
+        yx[v] = tbl[2 * (kl + 16 * v + j) + 1];
+    }
+    f32x4 acc[FV][KV];
+#pragma unroll
+    for (int u = 0; u < FV; u++)
+#pragma unroll
+        for (int v = 0; v < KV; v++) acc[u][v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const size_t imgBytes = ((size_t)(p.C * imgPixels - 1) * p.imgStride + p.N) * 4;
+    const __amdgpu_buffer_rsrc_t rImg = __builtin_amdgcn_make_buffer_rsrc((void*)p.images, 0, (int)imgBytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rHid = __builtin_amdgcn_make_buffer_rsrc((void*)p.hidActs, 0, (int)((size_t)p.F * M * p.N * 4), 0x00020000);
+    const unsigned OOB = 0xFFFFFFF0u;
+    const unsigned hstep = (unsigned)((size_t)16 * M * p.N * 4);
+    const int mBeg = chunk * p.modulesPerChunk, mEnd = min(M, mBeg + p.modulesPerChunk);
+    const int nIter = (p.N + 15) / 16, total = (mEnd - mBeg) * nIter;
+
+    int lm = mBeg, lnb = 0;  // load cursor: (module, first image of the block of 16)
+    auto load = [&](f32x4(&a)[FV], f32x4(&b)[KV]) {
+        const int y0 = p.pad + (lm / p.mX) * p.stride, x0 = p.pad + (lm % p.mX) * p.stride;
+        const bool nin = lnb + 4 * kk < p.N;
+        const unsigned hoff = (unsigned)(((size_t)(f0 + j) * M + lm) * p.N + lnb + 4 * kk) * 4u;
+#pragma unroll
+        for (int u = 0; u < FV; u++)
+            a[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rHid, nin ? hoff + u * hstep : OOB, 0, 0));
+#pragma unroll
+        for (int v = 0; v < KV; v++) {
+            bool inb = nin;
+            if (check) inb = inb && (unsigned)(y0 + (yx[v] >> 16)) < (unsigned)p.imgY && (unsigned)(x0 + (yx[v] & 0xffff)) < (unsigned)p.imgX;
+            const unsigned aoff = (unsigned)((off[v] + y0 * p.imgX + x0) * p.imgStride + lnb + 4 * kk) * 4u;
+            b[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rImg, inb ? aoff : OOB, 0, 0));
+        }
+        lnb += 16;
+        if (lnb >= p.N) {
+            lnb = 0;
+            if (lm + 1 < mEnd) lm++;  // (past the end: the last module again, never used)
+        }
+    };
+    auto compute = [&](const f32x4(&a)[FV], const f32x4(&b)[KV]) {
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int u = 0; u < FV; u++)
+#pragma unroll
+                for (int v = 0; v < KV; v++) acc[u][v] = mfma16(a[u][t], b[v][t], acc[u][v]);
+    };
+    f32x4 a0[FV], b0[KV], a1[FV], b1[KV];
+    load(a0, b0);
+    for (int it = 0; it < total; it += 2) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): set 0 has arrived, nothing else is in flight
+        __builtin_amdgcn_sched_barrier(0);
+        load(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
+        load(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < total) compute(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // acc[u][v][r] = dW[k = kb + 16 v + j][f = f0 + 16 u + 4 kk + r]
+    float* tb = p.targets + ((size_t)chunk * K + kb + j) * p.F + f0 + 4 * kk;
+    if (p.sT != 0.f) {
+        f32x4 old[FV][KV];
+#pragma unroll
+        for (int u = 0; u < FV; u++)
+#pragma unroll
+            for (int v = 0; v < KV; v++) old[u][v] = *reinterpret_cast<const f32x4*>(tb + (size_t)16 * v * p.F + 16 * u);
+#pragma unroll
+        for (int u = 0; u < FV; u++)
+#pragma unroll
+            for (int v = 0; v < KV; v++) *reinterpret_cast<f32x4*>(tb + (size_t)16 * v * p.F + 16 * u) = p.sT * old[u][v] + p.sO * acc[u][v];
+    } else {
+#pragma unroll
+        for (int u = 0; u < FV; u++)
+#pragma unroll
+            for (int v = 0; v < KV; v++) *reinterpret_cast<f32x4*>(tb + (size_t)16 * v * p.F + 16 * u) = p.sO * acc[u][v];
+    }
+}
+
 // column sums of the (chunks x cols) partials in a fixed order: grad = sT*grad + sum
 // One block per 16 columns: thread (r = tid/16, c = tid%16) sums rows r, r+16, ... in four interleaved
 // running sums, then the 16 row groups are combined through LDS in a fixed tree.
@@ -255,6 +366,13 @@ static int weight_acts_check(const float* images, const float* hidActs, float* t
     return MCN_OK;
 }
 
+// k_weight_acts_wide applies (given 16-byte operands): 16 KV rows per wave, 0 = no
+static int wide_kv(int K, int F, int groups) {
+    static const int off = getenv("MCN_WA_WIDE") ? !atoi(getenv("MCN_WA_WIDE")) : 0;
+    if (off || groups != 1 || F % 128 != 0) return 0;
+    return K % 96 == 0 ? 3 : K % 128 == 0 ? 4 : 0;
+}
+
 // modulesPerChunk modules are summed per output slab; targets has divup(M, modulesPerChunk) slabs.
 static int weight_acts_launch(const float* images, const float* hidActs, float* targets, int N, int imgStride,
                               int imgY, int imgX, int C, int F, int fs, int mY, int mX, int pad, int stride,
@@ -283,6 +401,17 @@ static int weight_acts_launch(const float* images, const float* hidActs, float* 
     if (lds < (size_t)KV * FV * 64 * 16) lds = (size_t)KV * FV * 64 * 16;
     MCN_REQUIRE(lds <= 64 * 1024, "weightActs: filter too large for the decode table (%zu bytes)", lds);
     p.tick = mcn_take_tick(s);
+    const int wkv = wide_kv(K, F, groups);
+    if (wkv && (long)chunks * (K / (32 * wkv)) * (F / 128) >= 128) {  // (fewer blocks than that: the split forms below fill the chip better)
+        const size_t imgBytes = (size_t)C * imgY * imgX * imgStride * 4, hidBytes = (size_t)F * M * N * 4;
+        if (vecn && imgBytes < (1u << 31) && hidBytes < (1u << 31) && ((uintptr_t)targets % 16) == 0) {
+            dim3 wgrid(chunks, K / (32 * wkv), F / 128);
+            MCN_REQUIRE(wgrid.y <= 65535 && wgrid.z <= 65535, "weightActs: grid too large");
+            if (wkv == 3) MCN_LAUNCH((k_weight_acts_wide<3>), wgrid, dim3(256), 32 * 3 * 8, s, p);
+            else MCN_LAUNCH((k_weight_acts_wide<4>), wgrid, dim3(256), 32 * 4 * 8, s, p);
+            return MCN_LAUNCH_CHECK("weightActs");
+        }
+    }
     if (KV == 3 && FV == 2) launch_bw2<3, 2>(p, grid, lds, vecn, s);
     else if (KV == 3) launch_bw2<3, 1>(p, grid, lds, vecn, s);
     else if (KV == 2 && FV == 2) launch_bw2<2, 2>(p, grid, lds, vecn, s);
@@ -533,6 +662,12 @@ static void launch_strip(const StripParams& p, const StripPlan& pl, dim3 grid, h
 // module split of the fused reduction: enough chunks to fill the chip, few enough to keep the
 // second pass negligible
 static int reduced_modules_per_chunk(int M, int K, int F) {
+    if (const int wkv = wide_kv(K, F, 1)) {  // a block of the wide form = 32 KV rows x 128 filters of a chunk; every wave walks the whole chunk
+        static const int wantBlocks = getenv("MCN_WA_WIDE_BLOCKS") ? atoi(getenv("MCN_WA_WIDE_BLOCKS")) : 384;
+        const int perChunk = (K / (32 * wkv)) * (F / 128);
+        int chunks = std::max(1, std::min(M, divup(wantBlocks, perChunk)));
+        return divup(M, chunks);
+    }
     const long tilesPerChunk = (long)divup(K, 48) * (F / 16);
     long want = divup(1024, (int)(tilesPerChunk > 0 ? tilesPerChunk : 1));  // chunks wanted (a chunk is a 4-wave block per tile)
     if (want > M / 4) want = M / 4 > 0 ? M / 4 : 1;                         // at least one module per wave (measured: conv2 23.1 -> 19.4 us vs two)

@@ -134,6 +134,9 @@ __global__ __launch_bounds__(64 * NW) void k_filter_acts(const FwdParams p) {
             compute(a1, b1);
         }
     }
+    // (an explicit one-batch-in-flight form -- unconditional loads, s_waitcnt vmcnt(0) before each issue, scheduling barriers, as
+    // in k_weight_acts_wide -- was measured slower here: local3 10.7 -> 15.7 us, local4 7.4 -> 9.2, DeepID2+ local3 60.3 -> 62.9.  A
+    // wave's share of K is one to four batches; the compiler's step-by-step waits inside a batch matter more than overlap.)
 
     bool mine[FV * NQ];  // which (filter vector, image quad) groups this wave stores
 #pragma unroll
@@ -490,12 +493,17 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
     int FV = best_fv(4), NQ = N > 64 ? 2 : 1;
     bool ksplit = false;
     auto waves = [&](int fv, int nq) { return (long)divup(N, 64 * nq) * M * (F / (16 * fv)); };
-    if (waves(1, 1) * 4 <= 4096 && K >= 128) {
+    // big unshared layers (DeepID2+ local3: 100 modules x 128 filters, K = 1152): 64 filters x 64 images per block, K split over its
+    // four waves -- 16-byte weight loads and 16 MFMAs per k-step and load pair instead of 4 (measured 75.9 -> 60.3 us; the
+    // eight-wave split with 32 filters: 81 us).  MCN_FA_BIG_LOCAL=0 restores the one-wave tiles.
+    static const bool bigLocalOn = !(getenv("MCN_FA_BIG_LOCAL") && atoi(getenv("MCN_FA_BIG_LOCAL")) == 0);
+    const bool bigLocal = bigLocalOn && !conv && vecn && K >= 512 && ftiles % 4 == 0 && waves(1, 1) * 4 > 4096 && waves(1, 1) * 4 <= 8192;
+    if ((waves(1, 1) * 4 <= 4096 && K >= 128) || bigLocal) {
         // few modules (the unshared local layers): one block per (module, filter vector, 64 images), its four
         // waves split K.  Wide filter vectors keep the weight rows read in long contiguous pieces.
         ksplit = true;
         NQ = 1;
-        FV = best_fv(3);
+        FV = bigLocal ? 4 : best_fv(3);
     } else {
         // tile choice: largest filter vector that divides the group's filter tiles, then shrink until
         // the launch has at least one wave per SIMD (1024 on MI355X)

@@ -23,6 +23,20 @@ def close(got, want, rtol=RTOL, atol=ATOL, what=''):
     assert err <= bound, '%s: max abs err %.3e > %.3e' % (what, err, bound)
 
 
+def close_but_for_decisions(got, want, tol, what='', atol=1e-9, outlier_frac=1e-3, outlier_factor=50):
+    """Gradients of a whole training step from two differently tiled forward passes (GPU vs oracle, 32 images per rank vs 128 on one
+    GPU).  Rounding differences stay within tol x max|want|; but a relu input or two max-pool candidates that lie within rounding
+    distance of each other get DECIDED differently now and then (tools/flip_probe.py: DeepID2+, one step -- all 290 entries of
+    local3's increments beyond 1e-4 x max sit in two (module, filter) columns of one pool window), and that moves one image's term
+    of one filter: a discrete difference of about 1/minibatch of a column.  So: at most `outlier_frac` of the entries beyond the
+    bound, none beyond `outlier_factor` times it."""
+    d = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    bound = tol * float(np.max(np.abs(want))) + atol
+    frac = float((d > bound).mean())
+    assert frac <= outlier_frac and float(d.max()) <= outlier_factor * bound, \
+        '%s: max abs err %.3e (bound %.3e), %.4f %% of the entries beyond the bound' % (what, float(d.max()), bound, 100 * frac)
+
+
 def dev(a):
     return capi.DeviceBuffer(array=np.ascontiguousarray(a, dtype=np.float32))
 

@@ -22,6 +22,7 @@ import ccn_loader
 
 ccn_loader.load()
 from test_net_gpu import Native, preset  # noqa: E402
+from kutil import close_but_for_decisions  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -86,9 +87,7 @@ def test_ranks_on_one_gpu_equal_the_single_gpu_step(name, steps, world, tmp_path
         want['%s.binc' % l['name']] = l['biasesInc']
         want['%s.b' % l['name']] = l['biases']
         for k, w in want.items():
-            err = float(np.max(np.abs(r0[k].astype(np.float64) - w)))
-            bound = tol * float(np.max(np.abs(w))) + 1e-9
-            assert err <= bound, '%s: max abs err %.3e > %.3e against the single-GPU step' % (k, err, bound)
+            close_but_for_decisions(r0[k], w, tol, k + ' against the single-GPU step')
             checked += 1
     assert checked >= 8
     for k, v in costs.items():

@@ -41,6 +41,8 @@ GEOMS = {
     'groups2': (10, 10, 16, 32, 3, 8, 8, 0, 1, 2, True),
     'local_groups2_pad': (7, 7, 8, 32, 3, 7, 7, -1, 1, 2, False),
     'odd_k': (9, 9, 1, 16, 3, 7, 7, 0, 1, 1, True),
+    'wide_pad_stride': (11, 9, 32, 128, 3, 6, 5, -1, 2, 1, True),   # k_weight_acts_wide with padding checks and stride 2
+    'wide_local_pad': (6, 6, 32, 256, 2, 7, 7, -1, 1, 1, False),    # ... KV = 4 (K = 128), two filter blocks, unshared
 }
 
 
@@ -156,6 +158,39 @@ def test_img_acts_shapes(name):
     close(d_out.numpy(), want, what=name)
 
 
+@pytest.mark.parametrize('N', [128, 96, 4])
+@pytest.mark.parametrize('sT', [0.0, 1.0])
+@pytest.mark.parametrize('name', ['conv2_plus', 'local3_plus'])
+def test_img_acts_narrow_form_of_the_layer_graph(name, sT, N):
+    """The layer graph asks for one wave per (pixel, 32 channels, 64 images) on wide layers (`img_acts_wide` = 0); with several
+    channel tiles a block is then the channel tiles of ONE pixel (BwdDataParams::waveCt).  Against the oracle at the kernel
+    tolerance, and the fused (max-pool undo + relu) epilogue == the unfused chain bit for bit."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(55)
+    hid = mk(rng, F * mY * mX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    t0 = mk(rng, C_ * imgY * imgX, N)
+    want = O.img_acts(hid, W, N, conv=conv, targets=t0.copy(), sT=sT, sO=1.0, **geo_kw(g))
+    cY, cX = 2 * imgY, 2 * imgX
+    acts = np.maximum(mk(rng, C_ * cY * cX, N), 0)
+    pooled = acts.reshape(C_, imgY, 2, imgX, 2, N).max(axis=(2, 4)).reshape(C_ * imgY * imgX, N)
+    call('mcn_set_thread_option', b'img_acts_wide', 0)
+    try:
+        d_out = dev(t0)
+        call('mcn_conv_img_acts' if conv else 'mcn_local_img_acts', dev(hid), dev(W), d_out, N, imgY, imgX, C_, F, fs, mY, mX,
+             pad, stride, groups, sT, 1.0, None)
+        close(d_out.numpy(), want, what='%s N=%d' % (name, N))
+        d_want = dev_empty(acts.shape, np.nan)
+        call('mcn_local_max_undo_neuron', dev(acts), d_out, dev(pooled), d_want, N, C_, cY, cX, 2, 0, 2, imgY, imgX, 1, 0.0, 0.0, None)
+        d_got = dev_empty(acts.shape, np.nan)
+        call('mcn_img_acts_max_undo', dev(hid), dev(W), dev(t0) if sT else None, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups,
+             1 if conv else 0, sT, 1.0, dev(acts), dev(pooled), d_got, 1, 0.0, 0.0, None)
+        assert np.array_equal(d_got.numpy(), d_want.numpy())
+    finally:
+        call('mcn_set_thread_option', b'img_acts_wide', 4)
+
+
 @pytest.mark.parametrize('N', RAGGED)
 @pytest.mark.parametrize('name', ['conv2_39x31', 'local4'])
 def test_img_acts_ragged_accumulate(name, N):
@@ -195,6 +230,27 @@ def test_weight_acts_shapes(name, ps):
         call('mcn_local_weight_acts', dev(img), dev(hid), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups,
              0.0, 0.01, None)
     close(d_out.numpy(), want, what=name)
+
+
+@pytest.mark.parametrize('N', [4, 20, 96, 128, 132])
+@pytest.mark.parametrize('name,ps', [('conv2_plus', 8), ('local3_plus', 1), ('local4_plus', 1), ('wide_pad_stride', 3), ('wide_local_pad', 1)])
+def test_weight_acts_wide_form_ragged_momentum(name, ps, N):
+    """k_weight_acts_wide (>= 128 filters, K a multiple of 96 / 128): one wave walks (module, 16 images) steps of a whole module
+    chunk; image counts that are not multiples of 16, chunks of several modules, padding, stride 2, momentum on the target."""
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(81)
+    img = mk(rng, C_ * imgY * imgX, N)
+    hid = mk(rng, F * mY * mX, N)
+    rows = C_ * fs * fs * (mY * mX // ps if conv else mY * mX)
+    t0 = mk(rng, rows, F, scale=0.01)
+    want = O.weight_acts(img, hid, N, partial_sum=ps, conv=conv, targets=t0.copy(), sT=0.9, sO=5e-4 / N, **geo_kw(g))
+    d_out = dev(t0)
+    args = [dev(img), dev(hid), d_out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups]
+    if conv:
+        args.append(ps)
+    call('mcn_conv_weight_acts' if conv else 'mcn_local_weight_acts', *args, 0.9, 5e-4 / N, None)
+    close(d_out.numpy(), want, what='%s N=%d' % (name, N))
 
 
 @pytest.mark.parametrize('N', RAGGED)
