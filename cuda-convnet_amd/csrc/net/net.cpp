@@ -205,6 +205,7 @@ void Layer::fpropFromPrev(PassType pt) {  // layer.cu:75-84
 
 void Layer::fprop(const std::vector<float*>& inputs, PassType pt) {  // layer.cu:92-114
     if (inputs.size() != _prev.size()) throw NetError("layer '" + _name + "': wrong number of inputs");
+    _net->beforeLayerFprop(this);
     _inputs = inputs;
     _acts = _actsTarget < 0 ? _ownActs.p : _inputs[_actsTarget];
     _rcvdF = (int)_prev.size();
@@ -337,12 +338,14 @@ void WeightLayer::bpropCommon(float* v, PassType pt) {  // layer.cu:306-317
     // two pieces of side-stream work: they start at once next to this layer's backward-data kernels, except for the
     // last weight layer of the pass, which has nothing left to hide behind and is split over both streams
     const bool last = _net->lastWeightLayerOfPass(this);
-    if (last && pt == PASS_TRAIN) _net->earlyUpdate();  // (queued ahead of this layer's own pieces, see there)
     // the bias gradient: a row sum queued for the pass's one batched launch -- unless the weight-gradient launch below
     // delivers it (conv, strip form).  The batch goes out with the LAST layer of the pass that adds to it, so that a last
     // layer without a bias piece of its own (DeepID's conv1) leaves nothing for the side stream to do at the very end.
     const bool biasHere = _biases->eps() > 0 && !(_biasInWgrad && pt == PASS_TRAIN && _net->fusedTailNow());
     const bool flushHere = _net->biasBatching() && _net->flushesBiasBatch(this, last);
+    // (queued ahead of this layer's own pieces; not when this layer still adds to -- and flushes -- the pass's bias batch: the
+    // early update reads the other layers' bias sums)
+    if (last && pt == PASS_TRAIN && !flushHere && !(biasHere && _net->biasBatching())) _net->earlyUpdate();
     if (biasHere || flushHere) {
         _net->deferSideWork([this, v, pt, biasHere, flushHere] {
             if (biasHere) {
@@ -1783,6 +1786,9 @@ void ConvNet::resetAfterError() {
     _gradPending = false;
     _exchangeWorkPending = false;
     _earlyUpdateIssued = false;
+    _earlyPos = 0;
+    _pendingMainGate = 0;
+    _pendingWeightGate = 0;
     _fusedTailNow = false;
     _sideWaitPending = false;
     _passNow.clear();
@@ -1931,7 +1937,7 @@ void ConvNet::allocate(int maxCases) {
     }
     // ... and the same plan with the latency-only tail launches of a step folded in (fusedTailNow)
     _fusedTailOk = false;
-    static const bool noFusedTail = getenv("MCN_NO_FUSED_TAIL") != nullptr || getenv("MCN_EARLY_SGD") != nullptr;
+    static const bool noFusedTail = getenv("MCN_NO_FUSED_TAIL") != nullptr;
     if (!dp && _fusion && !_hasSharing && !noFusedTail && biasBatching() && _sgdCount > 0) {
         std::vector<::mcn_sgd_item> fi;
         std::vector<::mcn_sgd_partials> fp;
@@ -2210,18 +2216,22 @@ bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
 // Most of the weight update, early: when a training pass reaches its LAST weight layer every other weight layer has queued
 // its backward-data kernels (the only readers of its weights left in this step) on the main stream and its gradients on the
 // side stream, so one launch on the side stream -- ordered after both by the fork that follows -- can update all of them
-// while the main stream still computes the last layer's gradient.  The update after the join then covers that last layer
-// only (DeepID2: conv1, 784 of 3.2 M parameters; 12 -> 3 us at the very end of the step).  Same kernel and records as the
-// one-launch update, so the weights are bit-identical.  Not in data-parallel mode (the update follows the all-reduce).
-// MEASURED (DeepID2, MI355X): 0.282 -> 0.289 ms / step -- from fc6's gradient on the side stream is as busy as the main
-// stream, and 11 us more on it move the end of the step out further than the shorter final update pulls it in.  Opt-in
-// (MCN_EARLY_SGD=1) until the side stream carries less.
+// while the main stream still computes the last layer's gradient.  The update after that covers the last layer only
+// (DeepID2: conv1, 784 of 3.2 M parameters), and the main stream's gate for the side stream comes AFTER it.  Same kernel and
+// records as the one-launch update (the fused-tail records where that plan is in use), so the weights are bit-identical.
+// Not in data-parallel mode (the update follows the all-reduce), not with shared weights, not under capture.
+// Round 2 measured this as a loss (DeepID2 0.282 -> 0.289 ms) when the join was an event wait and the early launch queued in
+// front of the last layer's own side-stream pieces; with stream gates, the last layer's gradient on the main stream and the
+// early launch the side stream's LAST kernel: DeepID2+ see DESIGN.md section 5.  MCN_NO_EARLY_SGD=1 switches it off.
 void ConvNet::earlyUpdate() {
-    static const bool off = getenv("MCN_EARLY_SGD") == nullptr;  // opt-in, see above
-    if (off || dataParallel() || !_fusion || _sgdCount == 0 || _passOrder.size() < 2 || _passNow != _passOrder) return;
-    if (!_splitPlans && _capturing) return;  // (allocates and copies: not while a stream is being captured)
+    static const bool off = getenv("MCN_NO_EARLY_SGD") != nullptr;
+    _earlyPos = 0;
+    if (off || dataParallel() || _hasSharing || !_fusion || _sgdCount == 0 || _passOrder.size() < 2 || _passNow != _passOrder) return;
+    if (!_gradStream || _profiling || _capturing || !gatesUsable()) return;
+    if (_fusedTailOk != _fusedTailNow) return;  // (a short minibatch: the plain plan, in one launch)
     if (!_splitPlans) {
         std::vector<::mcn_sgd_item> early, late;
+        std::vector<::mcn_sgd_partials> earlyP, lateP;
         for (auto& l : _layers) {
             std::vector<Weights*> ws_;
             l->collectWeights(ws_);
@@ -2229,7 +2239,13 @@ void ConvNet::earlyUpdate() {
             const bool visited = std::find(_passOrder.begin(), _passOrder.end(), dynamic_cast<WeightLayer*>(l.get())) != _passOrder.end();
             for (Weights* w : ws_) {
                 ::mcn_sgd_item it;
-                if (w->planItem(false, it)) (visited && !isLast ? early : late).push_back(it);
+                if (!w->planItem(false, it)) continue;
+                ::mcn_sgd_partials q = {nullptr, 0, 0, 1.f};
+                if (_fusedTailOk && w->partials.data && it.useGrad) {
+                    q.data = w->partials.data; q.count = w->partials.count; q.kind = w->partials.kind; q.scale = w->partials.scale;
+                }
+                (visited && !isLast ? early : late).push_back(it);
+                (visited && !isLast ? earlyP : lateP).push_back(q);
             }
         }
         _sgdEarlyCount = (int)early.size();
@@ -2237,21 +2253,26 @@ void ConvNet::earlyUpdate() {
         if (_sgdEarlyCount > 0) {
             const size_t pb = mcn_sgd_plan_bytes(_sgdEarlyCount);
             _sgdEarly.ensure((pb + 3) / 4);
-            chk(mcn_sgd_plan_build(early.data(), _sgdEarlyCount, _sgdEarly.p, pb, &_sgdEarlyBlocks, _stream), "sgd plan (early)");
+            chk(mcn_sgd_plan_build_fused(early.data(), earlyP.data(), _sgdEarlyCount, _sgdEarly.p, pb, &_sgdEarlyBlocks, _stream), "sgd plan (early)");
         }
         if (_sgdLateCount > 0) {
             const size_t pb = mcn_sgd_plan_bytes(_sgdLateCount);
             _sgdLate.ensure((pb + 3) / 4);
-            chk(mcn_sgd_plan_build(late.data(), _sgdLateCount, _sgdLate.p, pb, &_sgdLateBlocks, _stream), "sgd plan (late)");
+            chk(mcn_sgd_plan_build_fused(late.data(), lateP.data(), _sgdLateCount, _sgdLate.p, pb, &_sgdLateBlocks, _stream), "sgd plan (late)");
         }
         _splitPlans = true;
     }
     if (_sgdEarlyCount == 0) return;
     _earlyUpdateIssued = true;
-    deferSideWork([this] {
-        ProfScope ps(this, "net", "update (early)");
+    // two signals on the side stream: A in front of the early update -- every gradient piece and cost value of this step is
+    // behind it, the next forward pass may overwrite the activations -- and B (joinGradWork) behind it: the weights are ready
+    const int seqA = nextGateSeq();
+    _earlySeqA = seqA;
+    deferSideWork([this, seqA] {
+        signalGate(seqA);
         chk(mcn_sgd_update_planned(_sgdEarly.p, _sgdEarlyCount, _sgdEarlyBlocks, stream()), "sgd update (early)");
     }, 0, true);
+    _earlyPos = _deferred.size();  // (finishSideWork sends everything up to here to the side stream; 0 if a flush took it already)
 }
 
 void ConvNet::deferSideWork(std::function<void()> fn, int units, bool hold) {
@@ -2319,6 +2340,7 @@ void ConvNet::flushSideWork(size_t count) {
         _deferredUnits -= _deferred[i].second;
     }
     _deferred.erase(_deferred.begin(), _deferred.begin() + count);
+    _earlyPos = _earlyPos > count ? _earlyPos - count : 0;
     _gradPending = true;
     if (_capturing) {
         // graph capture: this thread issues the side stream's work itself -- the fork event pulls the side stream into the
@@ -2450,6 +2472,7 @@ void ConvNet::joinExchange() {
 void ConvNet::finishSideWork(bool deferHostWait) {
     // what is still deferred has no backward-data work left to hide behind: half goes to the side stream, the
     // rest runs on the main stream next to it
+    if (_earlyPos > 0) flushSideWork(_earlyPos);  // the early update and every piece queued before it: side stream
     if (_hasSharing && _gradStream && !_profiling) {
         flushSideWork(_deferred.size());  // shared matrices: every contribution on the side stream, in pass order
     } else if (_deferredUnits >= 2) {
@@ -2494,7 +2517,25 @@ void ConvNet::hostWaitSide() {
 
 // deferHostWait: the caller promises to call hostWaitSide() before it touches anything the side thread's closures read or
 // write (the pass state of the layers, the update counters); until then it may only queue work on the main stream.
-void ConvNet::joinGradWork(bool deferHostWait) {
+// The first layer of a forward pass that reads weights the early update writes waits for the side stream's signal B; the layers
+// in front of it (data, the pass's last weight layer -- updated on the main stream --, pools, neurons) run next to that update.
+void ConvNet::beforeLayerFprop(Layer* l) {
+    if (!_pendingWeightGate) return;
+    if (!dynamic_cast<WeightLayer*>(l) || (!_passOrder.empty() && l == static_cast<Layer*>(_passOrder.back()))) return;
+    awaitGate(_pendingWeightGate);
+    _pendingWeightGate = 0;
+}
+
+// keepWeightGate: the caller is a forward pass (beforeLayerFprop places the gate for the early update's weights)
+void ConvNet::joinGradWork(bool deferHostWait, bool keepWeightGate) {
+    if (_pendingMainGate) {
+        awaitGate(_pendingMainGate);
+        _pendingMainGate = 0;
+    }
+    if (_pendingWeightGate && !keepWeightGate) {
+        awaitGate(_pendingWeightGate);
+        _pendingWeightGate = 0;
+    }
     hostWaitSide();  // (left pending by an earlier join)
     if (_hasSharing && _gradStream && !_profiling && !_deferred.empty()) flushSideWork(_deferred.size());  // (never a sharer's piece on the main stream)
     if (!_deferred.empty()) {
@@ -2517,7 +2558,11 @@ void ConvNet::joinGradWork(bool deferHostWait) {
             flushBiasSums();
             signalGate(seq);
         });
-        awaitGate(seq);  // (sends an armed tick first: the side thread may be waiting for it)
+        // (an early update is on the side stream: the main stream's gate goes behind ITS update launch, updateWeights)
+        if (_earlyUpdateIssued && deferHostWait) {
+            _pendingMainGate = _earlySeqA;
+            _pendingWeightGate = seq;
+        } else awaitGate(seq);  // (sends an armed tick first: the side thread may be waiting for it)
         _gradPending = false;
         static const bool noDefer = getenv("MCN_NO_DEFER_WAIT") != nullptr;  // (A/B switch)
         if (deferHostWait && !dataParallel() && !noDefer) _sideWaitPending = true;
@@ -2543,7 +2588,7 @@ void ConvNet::joinGradWork(bool deferHostWait) {
 
 void ConvNet::fpropCurrent(PassType pt) {  // convnet.cu:213-219
     if (_failed) throw NetError("this data-parallel replica failed in an earlier step and has left its group: destroy the model on every rank");
-    joinGradWork();  // side-stream work of the previous minibatch (cost values in a test pass) reads buffers rewritten below
+    joinGradWork(false, true);  // side-stream work of the previous minibatch (cost values in a test pass) reads buffers rewritten below
     for (auto& l : _layers) l->reset();
     for (DataLayer* d : _dataLayers) {
         if (d->dataIdx < 0 || d->dataIdx >= (int)_curData.size()) throw NetError("data layer '" + d->name() + "': no data matrix " + std::to_string(d->dataIdx));
@@ -2570,7 +2615,7 @@ void ConvNet::fpropSlice(long start, long end, PassType pt) {
     end = std::min(end, _dp->numCases());
     _numCases = (int)(end - start);
     if (_numCases > _allocatedCases) throw NetError("minibatch larger than the allocated size");
-    joinGradWork();  // the slice buffers (labels) may still be read by cost kernels of the previous minibatch
+    joinGradWork(false, true);  // the slice buffers (labels) may still be read by cost kernels of the previous minibatch
     _dp->getSlice(start, end, _curData);
     fpropCurrent(pt);
 }
@@ -2621,6 +2666,10 @@ void ConvNet::updateWeights() {  // convnet.cu:190-194
         if (_earlyUpdateIssued) {  // this pass has updated everything but its last weight layer already
             _earlyUpdateIssued = false;
             if (_sgdLateCount > 0) chk(mcn_sgd_update_planned(_sgdLate.p, _sgdLateCount, _sgdLateBlocks, _stream), "sgd update (late)");
+            if (_pendingMainGate) {
+                awaitGate(_pendingMainGate);
+                _pendingMainGate = 0;
+            }
         } else if (_fusedTailNow) {
             chk(mcn_sgd_update_planned(_sgdFused.p, _sgdFusedCount, _sgdFusedBlocks, _stream), "sgd update (fused tail)");
         } else {

@@ -743,7 +743,8 @@ class ConvNet {
     void earlyUpdate();
     void deferLateWork(std::function<void()> fn);  // main stream, at the end of the pass (joinGradWork)
     void finishSideWork(bool deferHostWait = false);   // end of backward: place the remaining work, then join
-    void joinGradWork(bool deferHostWait = false);     // run whatever is still deferred on the main stream and wait for the side stream
+    void joinGradWork(bool deferHostWait = false, bool keepWeightGate = false);  // run whatever is still deferred on the main stream and wait for the side stream
+    void beforeLayerFprop(Layer* l);
     void hostWaitSide();     // the host-side half of a join whose wait was deferred
     int numCases() const { return _numCases; }
     int worldSize() const { return _world; }
@@ -883,6 +884,10 @@ class ConvNet {
     DBuf _sgdEarly, _sgdLate;
     int _sgdEarlyCount = 0, _sgdEarlyBlocks = 0, _sgdLateCount = 0, _sgdLateBlocks = 0;
     bool _splitPlans = false, _earlyUpdateIssued = false;
+    size_t _earlyPos = 0;      // deferred items up to and including the early update's (0: none queued)
+    int _pendingMainGate = 0;    // signal A (in front of the early update on the side stream) the main stream still has to wait for
+    int _pendingWeightGate = 0;  // signal B (behind it): before the first forward layer that reads the weights it writes
+    int _earlySeqA = 0;
     std::vector<double> _costHost;
     double _baseErr = 0;
 

@@ -177,3 +177,22 @@ def test_fused_update_tail_equals_separate_launches_bitwise(name):
                 assert np.array_equal(a, b), '%s %s[%d] differs between the fused and the separate tail' % (la['name'], key, i)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), '%s %s differs between the fused and the separate tail' % (la['name'], key)
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_early_update_on_the_side_stream_equals_the_one_launch_update_bitwise(name):
+    """From the second step on every weight layer but the pass's last one is updated by a launch on the side stream while the main
+    stream still computes the last layer's gradient, and the next forward pass starts before that launch has finished
+    (ConvNet::earlyUpdate, beforeLayerFprop).  Same records, same kernel: identical weights and costs after three steps;
+    a missing wait shows up here as a difference.  MCN_NO_EARLY_SGD=1: everything in one launch after the join."""
+    La, ca = train3(name, {})
+    Lb, cb = train3(name, {'MCN_NO_EARLY_SGD': '1'})
+    assert ca == cb, (ca, cb)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between the early and the one-launch update' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between the early and the one-launch update' % (la['name'], key)

@@ -13,7 +13,13 @@ import sys
 path = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/prof/bench_kernel_trace.csv'
 mode = sys.argv[2] if len(sys.argv) > 2 else '60'
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_sgd_planned' in r['Kernel_Name']]
+# a step ends with the update launch on the MAIN queue (the one that runs the forward pass; the early update of the other
+# weight layers runs on the side queue and may end after it)
+queues = {}
+for r in rows:
+    queues[r['Queue_Id']] = queues.get(r['Queue_Id'], 0) + (0 if 'k_stream_' in r['Kernel_Name'] else 1)
+main_q = max(queues, key=queues.get)
+idx = [i for i, r in enumerate(rows) if 'k_sgd_planned' in r['Kernel_Name'] and r['Queue_Id'] == main_q]
 
 
 def step_rows(k):
