@@ -379,7 +379,7 @@ def main():
                                'frac': top['frac'], 'traffic': None, 'kernel': top['op'], 'avg_us': top['avg_us']}
             # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
             # under profiles/ with the gfx950 correction applied (they cannot be collected inside this process)
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_traffic_by_op.json')
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_traffic_by_op.json')
             if a.workload == 'deepid2' and mb == 128 and os.path.exists(pmc):
                 rec = json.load(open(pmc)).get(top['op'])
                 # a record is only as good as the kernel it was taken from: it names the device symbol, which must still be

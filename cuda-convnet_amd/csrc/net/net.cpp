@@ -666,7 +666,7 @@ bool LocalLayer::planFusedTail(int numCases) {
         w.partials.count = mcn_conv_weight_acts_partials_count(numCases, numCases, (int)_imgSizeY[i], (int)_imgSizeX[i], channels, _filters,
                                                                (int)_filterSize[i], _modulesY, _modulesX, (int)_stride[i], (int)_groups[i], &biasCapable);
         if (w.partials.count <= 0) w.partials = Weights::Partials();
-        static const bool noBiasInWgrad = getenv("MCN_NO_BIAS_IN_WGRAD") != nullptr;  // (A/B switch)
+        const bool noBiasInWgrad = getenv("MCN_NO_BIAS_IN_WGRAD") != nullptr;  // (A/B switch; read per model: tests toggle it in one process)
         if (i == 0 && w.partials.count > 0 && biasCapable && _sharedBiases && _biases->eps() > 0 && !noBiasInWgrad) {
             // the strip kernel stages every gradient row of the layer: it sums them for the shared biases on the way
             _biasParts.ensure((size_t)w.partials.count * _filters);
@@ -1576,6 +1576,8 @@ double Cost::value() const {
 ConvNet::ConvNet(const std::vector<Params>& layers, int minibatchSize, int deviceID) : _minibatchSize(minibatchSize), _deviceID(deviceID) {
     if (minibatchSize <= 0) throw NetError("minibatch size must be positive");
     _fusion = getenv("MCN_NO_FUSION") == nullptr;  // debugging aid: run every layer as its own kernel(s)
+    _earlyOff = getenv("MCN_NO_EARLY_SGD") != nullptr;  // (per model, like every switch a test toggles inside one process)
+    _earlyMinElems = getenv("MCN_EARLY_SGD_MIN_ELEMS") ? (size_t)atol(getenv("MCN_EARLY_SGD_MIN_ELEMS")) : (size_t)8 << 20;
     for (const Params& p : layers) {  // convnet.cu:86-134
         const std::string& t = pstr(p, "type");
         Layer* l;
@@ -1937,7 +1939,7 @@ void ConvNet::allocate(int maxCases) {
     }
     // ... and the same plan with the latency-only tail launches of a step folded in (fusedTailNow)
     _fusedTailOk = false;
-    static const bool noFusedTail = getenv("MCN_NO_FUSED_TAIL") != nullptr;
+    const bool noFusedTail = getenv("MCN_NO_FUSED_TAIL") != nullptr;  // (read per model: tests toggle it in one process)
     if (!dp && _fusion && !_hasSharing && !noFusedTail && biasBatching() && _sgdCount > 0) {
         std::vector<::mcn_sgd_item> fi;
         std::vector<::mcn_sgd_partials> fp;
@@ -2224,9 +2226,8 @@ bool ConvNet::lastWeightLayerOfPass(WeightLayer* wl) {
 // front of the last layer's own side-stream pieces; with stream gates, the last layer's gradient on the main stream and the
 // early launch the side stream's LAST kernel: DeepID2+ see DESIGN.md section 5.  MCN_NO_EARLY_SGD=1 switches it off.
 void ConvNet::earlyUpdate() {
-    static const bool off = getenv("MCN_NO_EARLY_SGD") != nullptr;
     _earlyPos = 0;
-    if (off || dataParallel() || _hasSharing || !_fusion || _sgdCount == 0 || _passOrder.size() < 2 || _passNow != _passOrder) return;
+    if (_earlyOff || dataParallel() || _hasSharing || !_fusion || _sgdCount == 0 || _passOrder.size() < 2 || _passNow != _passOrder) return;
     if (!_gradStream || _profiling || _capturing || !gatesUsable()) return;
     if (_fusedTailOk != _fusedTailNow) return;  // (a short minibatch: the plain plan, in one launch)
     if (!_splitPlans) {
@@ -2250,6 +2251,8 @@ void ConvNet::earlyUpdate() {
         }
         _sgdEarlyCount = (int)early.size();
         _sgdLateCount = (int)late.size();
+        _sgdEarlyElems = 0;
+        for (const auto& it : early) _sgdEarlyElems += it.n;
         if (_sgdEarlyCount > 0) {
             const size_t pb = mcn_sgd_plan_bytes(_sgdEarlyCount);
             _sgdEarly.ensure((pb + 3) / 4);
@@ -2262,7 +2265,10 @@ void ConvNet::earlyUpdate() {
         }
         _splitPlans = true;
     }
-    if (_sgdEarlyCount == 0) return;
+    // Worth it only where the update launch is long next to what the split costs (a second update launch, a second gate on the main
+    // stream and one more hand-shake with the side thread, about 10 us): DeepID2+ (22 M parameters, 67 us) gains 7 us per step,
+    // DeepID2 (3.2 M, 13 us) gains nothing and its traced step shows the main thread waiting for the side thread.
+    if (_sgdEarlyCount == 0 || _sgdEarlyElems < _earlyMinElems) return;
     _earlyUpdateIssued = true;
     // two signals on the side stream: A in front of the early update -- every gradient piece and cost value of this step is
     // behind it, the next forward pass may overwrite the activations -- and B (joinGradWork) behind it: the weights are ready

@@ -884,6 +884,8 @@ class ConvNet {
     DBuf _sgdEarly, _sgdLate;
     int _sgdEarlyCount = 0, _sgdEarlyBlocks = 0, _sgdLateCount = 0, _sgdLateBlocks = 0;
     bool _splitPlans = false, _earlyUpdateIssued = false;
+    size_t _sgdEarlyElems = 0, _earlyMinElems = (size_t)8 << 20;
+    bool _earlyOff = false;
     size_t _earlyPos = 0;      // deferred items up to and including the early update's (0: none queued)
     int _pendingMainGate = 0;    // signal A (in front of the early update on the side stream) the main stream still has to wait for
     int _pendingWeightGate = 0;  // signal B (behind it): before the first forward layer that reads the weights it writes

@@ -185,7 +185,7 @@ def test_early_update_on_the_side_stream_equals_the_one_launch_update_bitwise(na
     stream still computes the last layer's gradient, and the next forward pass starts before that launch has finished
     (ConvNet::earlyUpdate, beforeLayerFprop).  Same records, same kernel: identical weights and costs after three steps;
     a missing wait shows up here as a difference.  MCN_NO_EARLY_SGD=1: everything in one launch after the join."""
-    La, ca = train3(name, {})
+    La, ca = train3(name, {'MCN_EARLY_SGD_MIN_ELEMS': '0'})  # (by default only nets with a long update launch split it)
     Lb, cb = train3(name, {'MCN_NO_EARLY_SGD': '1'})
     assert ca == cb, (ca, cb)
     for la, lb in zip(La, Lb):

@@ -59,12 +59,19 @@ def report(name, fn, flops, nbytes):
     print('%-28s %8.2f us  %7.2f TFLOP/s  %7.1f GB/s' % (name, us, flops / us / 1e6, nbytes / us / 1e3), flush=True)
 
 
+def skip(flt, name, family):
+    """layer filter: substring of the name (or of the family: 'conv' / 'fc' select all); 'conv2$' = exactly conv2"""
+    if flt.endswith('$'):
+        return name != flt[:-1]
+    return bool(flt) and flt not in name and flt not in family
+
+
 def main():
     flt = sys.argv[1] if len(sys.argv) > 1 else ''
     rng = np.random.default_rng(0)
     ws = capi.workspace(64 << 20)
     for name, (imgY, imgX, C_, F, fs, mY, mX, pad, stride, conv) in CONVS.items():
-        if flt and flt not in name and flt not in 'conv':
+        if skip(flt, name, 'conv'):
             continue
         M, K = mY * mX, C_ * fs * fs
         img = dev(rng.standard_normal((C_ * imgY * imgX, N)).astype(np.float32))
@@ -92,7 +99,7 @@ def main():
         else:
             report(name + ' weightActs', (lambda: call('mcn_local_weight_acts', img, hid, dW, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, 0.9, 1.0, None)), flops, nbytes)
     for name, (O_, I) in FCS.items():
-        if flt and flt not in name and flt not in 'fc':
+        if skip(flt, name, 'fc'):
             continue
         W = dev((rng.standard_normal((O_, I)) * 0.01).astype(np.float32))
         X = dev(rng.standard_normal((I, N)).astype(np.float32))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_pmc_traffic_by_op.json from the FETCH_SIZE / WRITE_SIZE passes of pmc_round.sh (gpurun_out/pmc_<tag>_{fetch,write}.csv).
+"""profiles/r03_pmc_traffic_by_op.json from the FETCH_SIZE / WRITE_SIZE passes of pmc_round3.sh (gpurun_out/pmc_<tag>_{fetch,write}.csv).
 
 Per bench op label: the kernels one call of that op launches, their HBM traffic per launch (PMC, corrected as
 MI355X_MICROARCH.md's HBM / rocprofv3 section prescribes for gfx950: FETCH_SIZE counts 64 B per 128 B request of the wide reads
@@ -29,27 +29,40 @@ def conv_bytes(imgY, imgX, C, F, fs, mY, mX, conv):
 
 CONV2 = conv_bytes(26, 26, 16, 32, 3, 24, 24, True)
 LOCAL3 = conv_bytes(12, 12, 32, 48, 3, 10, 10, False)
+LOCAL4 = conv_bytes(5, 5, 48, 64, 2, 4, 4, False)
 CONV1 = conv_bytes(55, 55, 3, 16, 4, 52, 52, True)
+CONV2P = conv_bytes(26, 26, 32, 128, 3, 24, 24, True)
+LOCAL3P = conv_bytes(12, 12, 128, 128, 3, 10, 10, False)
 FC6 = (10575 * 160 * F4, 160 * N * F4, 10575 * N * F4)  # W, X, Y
+ROUND = 'r03'
+
+
+def undo_bytes(g):  # imgActs continued through pool + relu: hidActs, W, the pool's input (4x the image) and output, the pool input's gradient
+    return g[1] + g[2] + 4 * g[0] + g[0] + 4 * g[0]
+
 
 # op label: (tag, [kernel name prefixes as rocprofv3 prints them], algorithmic bytes per call, note)
 OPS = {
-    # imgActs continued through pool + relu: reads hidActs, W, the pool's input (4x the image) and output, writes the pool input's gradient
-    'conv2.bpropActs[0]': ('iau2', ['void k_img_acts<1, 1, true, 2, 2, 2>'], CONV2[1] + CONV2[2] + 4 * CONV2[0] + CONV2[0] + 4 * CONV2[0],
-                           'mcn_img_acts_max_undo (imgActs + max-pool undo + relu gradient in one launch)'),
-    'local3.bpropActs[0]': ('iau3', ['void k_img_acts<1, 1, true, 2, 2, 2>'], LOCAL3[1] + LOCAL3[2] + 4 * LOCAL3[0] + LOCAL3[0] + 4 * LOCAL3[0],
-                            'mcn_img_acts_max_undo'),
+    'conv2.bpropActs[0]': ('iau2', ['void k_img_acts<1, 1, true, 2, 2, 2>'], undo_bytes(CONV2), 'mcn_img_acts_max_undo (imgActs + max-pool undo + relu gradient in one launch)'),
+    'local3.bpropActs[0]': ('iau3', ['void k_img_acts<1, 1, true, 2, 2, 2>'], undo_bytes(LOCAL3), 'mcn_img_acts_max_undo'),
+    'local4.bpropActs[0]': ('ia4', ['void k_img_acts<1, 1, true, 2, 4, 2>'], undo_bytes(LOCAL4), 'mcn_img_acts_max_undo, four waves per pixel'),
     'fc6.fprop[0]': ('fc6', ['void k_fc_nn_lds<10>'], FC6[0] + FC6[1] + FC6[2], 'forward product + bias + softmax stage 1'),
     'fc6.bpropActs[0]': ('fc6', ['void k_fc_tn_split<5, 6>', 'k_fc_tn_reduce'], FC6[0] + FC6[1] + FC6[2],
-                         'K = 10575 split over 60 blocks per tile: partial slabs written and read once more (k_fc_tn_reduce runs for both fc6 shapes of the pass: its average covers fc6 and fc6+)'),
+                         'K = 10575 split over 60 blocks per tile: partial slabs written and read once more'),
     'fc6.bpropWeights[0]': ('fc6', ['void k_fc_nt_lds<10>'], 2 * FC6[0] + FC6[1] + FC6[2], 'dW = mom * dW + eps/N dY X^T: dW read and written'),
     'conv1.bpropWeights[0]': ('wa1', ['void k_conv_wgrad_strip<3, 1>', 'k_reduce_chunks'], CONV1[0] + CONV1[1] + CONV1[2],
-                              'k_reduce_chunks averaged over conv1 and conv1+'),
-    'conv2.bpropWeights[0]': ('wa2', ['void k_weight_acts<2, 2, 2>', 'k_reduce_chunks'], CONV2[0] + CONV2[1] + CONV2[2], 'k_reduce_chunks averaged over conv2 and conv2+'),
-    # not an operation of the DeepID2 step: the DeepID2+ conv2 backward-data product alone (tools/kbench.py conv2+), wide form
-    'kbench conv2+ imgActs': ('iaw', ['void k_img_acts<2, 1, true, 4, 4, 0>'], sum(conv_bytes(26, 26, 32, 128, 3, 24, 24, True)),
-                              'four waves per pixel, two channel tiles each: every pixel re-reads the gradient rows of the <= 9 modules covering it (through L2)'),
+                              'kbench runs the reduced entry point; in the single-GPU step the chunk sum rides in the update launch'),
+    'conv2.bpropWeights[0]': ('wa2', ['void k_weight_acts<2, 2, 2>', 'k_reduce_chunks'], CONV2[0] + CONV2[1] + CONV2[2], ''),
+    'local3.bpropWeights[0]': ('wa3', ['void k_weight_acts<3, 1, 2>'], LOCAL3[0] + LOCAL3[1] + 2 * LOCAL3[2], 'inc = mom * inc + eps/N g: the increments are read and written'),
+    'local4.bpropWeights[0]': ('wa4', ['void k_weight_acts<1, 1, 2>'], LOCAL4[0] + LOCAL4[1] + 2 * LOCAL4[2], ''),
     'local3.fprop[0]': ('fa', ['void k_filter_acts<3, 1, 9, true, true, 8>'], sum(LOCAL3), ''),
+    'local4.fprop[0]': ('fa', ['void k_filter_acts<2, 1, 6, true, true, 8>'], sum(LOCAL4), ''),
+    # DeepID2+ (tools/kbench.py '+' shapes): the round-3 kernels
+    'deepid2plus local3.fprop[0]': ('fa', ['void k_filter_acts<4, 1, 4, true, true, 4>'], sum(LOCAL3P), '64 filters x 64 images per block, K split over four waves: each image half reads the module\'s weight slab'),
+    'deepid2plus local3.bpropWeights[0]': ('wa3', ['void k_weight_acts_wide<3>'], LOCAL3P[0] + LOCAL3P[1] + 2 * LOCAL3P[2], 'k_weight_acts_wide; increments read and written'),
+    'deepid2plus conv2.bpropWeights[0]': ('wa2p', ['void k_weight_acts_wide<3>', 'k_reduce_chunks'], sum(CONV2P), 'k_weight_acts_wide over 144 chunks of 4 modules (21 MB of partials written and read once) + k_reduce_chunks'),
+    'deepid2plus local3.bpropActs[0]': ('ian', ['void k_img_acts<2, 1, true, 1, 1, 2>'], undo_bytes(LOCAL3P), 'one wave per (pixel, 32 channels, 64 images), a block = the four channel tiles of one pixel (img_acts_wide = 0, what the layer graph runs)'),
+    'deepid2plus conv2.bpropActs[0]': ('ian2', ['void k_img_acts<2, 1, true, 1, 1, 2>'], undo_bytes(CONV2P), 'one wave per (pixel, 32 channels, 64 images) (img_acts_wide = 0)'),
 }
 
 
@@ -91,14 +104,14 @@ def main():
                    'correction': 'gfx950: FETCH_SIZE counts 64 B per 128 B request of wide reads -> x2; WRITE_SIZE exact; KB',
                    'traffic_bytes_per_launch': int(total), 'algorithmic_bytes_per_launch': int(algo),
                    'traffic_over_algorithmic': round(total / algo, 2),
-                   'collected_with': 'pmc_round.sh: pmc_passes.sh %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs over tools/kbench.py)' % tag}
+                   'collected_with': 'pmc_round3.sh: pmc_passes.sh %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs over tools/kbench.py)' % tag}
         if note:
             out[op]['note'] = note
         for ps in ('fetch', 'write', 'sq1', 'sq2'):
             src = os.path.join(OUT, 'pmc_%s_%s.csv' % (tag, ps))
             if os.path.exists(src):
-                shutil.copy(src, os.path.join(PROF, 'r02_pmc_%s_%s.csv' % (tag, ps)))
-    json.dump(out, open(os.path.join(PROF, 'r02_pmc_traffic_by_op.json'), 'w'), indent=1)
+                shutil.copy(src, os.path.join(PROF, '%s_pmc_%s_%s.csv' % (ROUND, tag, ps)))
+    json.dump(out, open(os.path.join(PROF, ROUND + '_pmc_traffic_by_op.json'), 'w'), indent=1)
     for op, r in out.items():
         print('%-24s %6.1f MB / launch  (algorithmic %6.1f MB, x%.2f)  %s' % (op, r['traffic_bytes_per_launch'] / 1e6, r['algorithmic_bytes_per_launch'] / 1e6,
                                                                                r['traffic_over_algorithmic'], ' '.join(r['kernel_symbols'])))
