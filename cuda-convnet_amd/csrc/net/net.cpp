@@ -2038,6 +2038,23 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         const char* env = getenv("MCN_BUCKET_MB");
         _bucketFloats = (size_t)((env ? atof(env) : 4.0) * 1024 * 1024 / 4);
         allocate(_minibatchSize);  // every weight matrix now needs a gradient buffer in the arena
+        // Warm the communicator up on both streams that carry collectives (exchange stream; main stream: the in-line last
+        // bucket) with the sizes of a step: RCCL builds its channels and connections inside the FIRST collectives, which can
+        // take seconds with eight ranks -- longer than a stream gate waits before it reports a dead stream.  The arena is
+        // all zeros here, and a sum of zeros leaves it so.
+        chk(mcn_stream_sync(_stream), "stream sync");
+        chk(mcn_allreduce_sum(_comm, _gradArena.p, _gradArena.cap, _commStream), "all-reduce (warm-up)");
+        if (_gradArena.cap >= (size_t)64 * (world + 1)) {
+            chk(mcn_comm_group_begin(), "group begin");
+            chk(mcn_allgather(_comm, _gradArena.p, _gradArena.p + 64, 64, _commStream), "all-gather (warm-up)");
+            chk(mcn_comm_group_end(), "group end");
+        }
+        chk(mcn_stream_sync(_commStream), "stream sync");
+        chk(mcn_allreduce_sum(_comm, _gradArena.p, std::min<size_t>(_gradArena.cap, 8192), _stream), "all-reduce (warm-up)");
+        chk(mcn_stream_sync(_stream), "stream sync");
+        // replicas wait for each other inside every collective (a peer's first steps page code in): a gate that depends on the
+        // exchange stream must outlast that
+        if (world > 1) _gateTimeoutMs = 120000;
     }
 }
 
@@ -2059,20 +2076,19 @@ void ConvNet::sync() {
 }
 
 // ---- side-stream submission -----------------------------------------------------------------
-static constexpr int kGateTimeoutMs = 5000;
 // (the self-tests at start-up cover the pairs of streams that gate each other: main / side here, main / exchange in initComm)
 bool ConvNet::gatesUsable() const { return _gateOk && !_capturing && !g_noHostWait && !_profiling; }
 bool ConvNet::g_noHostWaitFlag() { return g_noHostWait; }
 void ConvNet::signalCommGate(int seq) { chk(mcn_stream_signal(_commGate, seq, _commStream), "stream signal (exchange)"); }
 void ConvNet::awaitCommGate(int seq) {
     const auto t0 = std::chrono::steady_clock::now();
-    chk(mcn_stream_gate(_commGate, seq, kGateTimeoutMs, _stream), "stream gate (exchange)");
+    chk(mcn_stream_gate(_commGate, seq, _gateTimeoutMs, _stream), "stream gate (exchange)");
     g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 void ConvNet::signalGate(int seq) { chk(mcn_stream_signal(_gate, seq, stream()), "stream signal"); }
 void ConvNet::awaitGate(int seq) {
     const auto t0 = std::chrono::steady_clock::now();
-    chk(mcn_stream_gate(_gate, seq, kGateTimeoutMs, _stream), "stream gate");
+    chk(mcn_stream_gate(_gate, seq, _gateTimeoutMs, _stream), "stream gate");
     g_eventCallMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 void* ConvNet::stream() const { return t_stream == 1 ? _gradStream : t_stream == 2 ? _commStream : _stream; }
@@ -2366,7 +2382,7 @@ void ConvNet::flushSideWork(size_t count) {
         t_stream = 1;
         const auto t0 = std::chrono::steady_clock::now();
         if (forkEvent) chk(timedStreamWait(_gradStream, forkEvent), "wait event");
-        else if (gateFork) chk(mcn_stream_gate(_forkGate, tick, kGateTimeoutMs, _gradStream), "stream gate (fork)");
+        else if (gateFork) chk(mcn_stream_gate(_forkGate, tick, _gateTimeoutMs, _gradStream), "stream gate (fork)");
         else awaitTick(tick);
         const auto t1 = std::chrono::steady_clock::now();
         const uint64_t l0 = mcn_launch_ns();
@@ -2852,8 +2868,8 @@ void ConvNet::flushBuckets(bool force) {
     float* buf = _gradArena.p + _sentUpTo;
     const size_t count = end - _sentUpTo;
     _commSub.push([this, evMain, evSide, tickMain, tickSide, gateMain, gateSide, buf, count] {
-        if (gateMain) chk(mcn_stream_gate(_mainToComm, gateMain, kGateTimeoutMs, _commStream), "stream gate (bucket)");
-        if (gateSide) chk(mcn_stream_gate(_sideToComm, gateSide, kGateTimeoutMs, _commStream), "stream gate (bucket)");
+        if (gateMain) chk(mcn_stream_gate(_mainToComm, gateMain, _gateTimeoutMs, _commStream), "stream gate (bucket)");
+        if (gateSide) chk(mcn_stream_gate(_sideToComm, gateSide, _gateTimeoutMs, _commStream), "stream gate (bucket)");
         if (evMain) chk(timedStreamWait(_commStream, evMain), "wait event");
         if (evSide) chk(timedStreamWait(_commStream, evSide), "wait event");
         if (tickMain) awaitTick(tickMain, _tickFlag);

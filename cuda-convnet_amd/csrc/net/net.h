@@ -887,6 +887,7 @@ class ConvNet {
     size_t _sgdEarlyElems = 0, _earlyMinElems = (size_t)8 << 20;
     bool _earlyOff = false;
     size_t _earlyPos = 0;      // deferred items up to and including the early update's (0: none queued)
+    int _gateTimeoutMs = 5000;   // a gate that spins longer reports a dead stream at the next sync()
     int _pendingMainGate = 0;    // signal A (in front of the early update on the side stream) the main stream still has to wait for
     int _pendingWeightGate = 0;  // signal B (behind it): before the first forward layer that reads the weights it writes
     int _earlySeqA = 0;
