@@ -380,8 +380,8 @@ def main():
             # HBM bytes per launch from the PMC counters: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
             # under profiles/ with the gfx950 correction applied (they cannot be collected inside this process)
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03_pmc_traffic_by_op.json')
-            if a.workload == 'deepid2' and mb == 128 and os.path.exists(pmc):
-                rec = json.load(open(pmc)).get(top['op'])
+            if a.workload in ('deepid2', 'deepid2plus') and mb == 128 and os.path.exists(pmc):
+                rec = json.load(open(pmc)).get(top['op'] if a.workload == 'deepid2' else 'deepid2plus ' + top['op'])
                 # a record is only as good as the kernel it was taken from: it names the device symbol, which must still be
                 # in the library this run loaded (round 1 shipped a record of a kernel variant the tree no longer launched)
                 from cuda_convnet_amd import capi

@@ -404,6 +404,7 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
         p.waveCt = 1;
         grid = dim3(divup(N, 64 * NQ), imgPixels, groups * divup(fc, 16 * CV) / 4);
     }
+    if (CV > 2 || NQ != 1) ksplit = 0;  // (the pixel-split forms exist for one or two channel tiles and 64 images: never take a tick for a launch that does not happen)
     switch (CV) {
         case 4: launch_bd1<4>(p, NQ, grid, vecn, pipelined, 0, s); break;
         case 3: launch_bd1<3>(p, NQ, grid, vecn, pipelined, 0, s); break;

@@ -227,12 +227,20 @@ static PyObject* pinnedArray(PyObject*, PyObject* args) {
     void* p = nullptr;
     const size_t bytes = (size_t)rows * cols * sizeof(float);
     if (mcn_host_alloc(&p, bytes) != MCN_OK) { PyErr_SetString(PyExc_RuntimeError, mcn_last_error()); return nullptr; }
+    // the capsule owns the allocation from here on: every later failure only drops references
+    PyObject* cap = PyCapsule_New(p, "mcn_pinned", pinnedCapsuleFree);
+    if (!cap) {
+        mcn_host_free(p);
+        return nullptr;
+    }
     npy_intp dims[2] = {rows, cols};
     PyObject* arr = PyArray_SimpleNewFromData(2, dims, NPY_FLOAT32, p);
-    PyObject* cap = PyCapsule_New(p, "mcn_pinned", pinnedCapsuleFree);
-    if (!arr || !cap || PyArray_SetBaseObject((PyArrayObject*)arr, cap) != 0) {
-        Py_XDECREF(arr);
-        mcn_host_free(p);
+    if (!arr) {
+        Py_DECREF(cap);
+        return nullptr;
+    }
+    if (PyArray_SetBaseObject((PyArrayObject*)arr, cap) != 0) {  // (steals the capsule's reference, also when it fails)
+        Py_DECREF(arr);
         return nullptr;
     }
     pinnedRanges[(uintptr_t)p] = (uintptr_t)p + bytes;

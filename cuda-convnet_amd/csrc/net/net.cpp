@@ -32,13 +32,17 @@ static thread_local int t_stream = 0;  // which stream this submitting thread fe
 // side thread polls -- it has nothing else to do, and launches the moment the main stream's kernel has finished).
 // Default: the side thread polls.  MCN_HOST_WAIT overrides (0: every wait queued).
 static const int g_hostWaitMask = getenv("MCN_HOST_WAIT") ? atoi(getenv("MCN_HOST_WAIT")) : 2;
-static bool g_noHostWait = false;  // (stream capture in progress: events cannot be queried)
+static std::atomic<bool> g_noHostWait{false};  // (stream capture in progress: events cannot be queried; read by every submitting thread)
 int timedStreamWait(void* s, void* e) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc = MCN_OK;
     if (!g_noHostWait && t_stream <= 2 && ((g_hostWaitMask >> t_stream) & 1)) {
         int q;
-        while ((q = mcn_event_query(e)) == 0) {}
+        unsigned spin = 0;
+        while ((q = mcn_event_query(e)) == 0) {  // (a stream that hangs without faulting: give up like awaitTick does)
+            if ((++spin & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60))
+                throw NetError("an event a submitting thread polls for was not reached within 60 s");
+        }
         if (q < 0) rc = q;
     } else {
         rc = mcn_stream_wait_event(s, e);
@@ -1389,6 +1393,9 @@ void DataProvider::prefetch(const CPUData& d) {
     _nextTicket = up.push([this, d] {
         Uploader& u = _net->uploader();
         if (!_evNext) chk(mcn_event_create_sync(&_evNext), "event");
+        // the spare slot held the batch trained before: the copy stream starts behind everything the compute stream had
+        // queued when that batch was swapped out (adoptPrefetched)
+        if (_slotFreeRecorded.load()) chk(mcn_stream_wait_event(u.stream(), _evSlotFree), "wait event");
         while (_devNext.size() < d.mats.size()) {
             _devNext.emplace_back(new DBuf());
             _tiledNext.emplace_back(new DBuf());
@@ -1436,10 +1443,11 @@ void DataProvider::adoptPrefetched() {
     _onDevice = true;
     _host = CPUData();
     _nextTicket.store(0);
-    _adoptQueued.store(false);  // the spare slot (the batch trained before) may be overwritten from here on
+    if (!_evSlotFree) chk(mcn_event_create_sync(&_evSlotFree), "event");
+    chk(mcn_event_record(_evSlotFree, _net->mainStream()), "event record");  // (the worker joined the side stream before it got here)
+    _slotFreeRecorded.store(true);
+    _adoptQueued.store(false);  // the spare slot (the batch trained before) may be overwritten from here on -- behind that event
 }
-
-void DataProvider::markBatchIssued() {}
 
 // ---- streamed minibatches: the batch stays on the host (reference: batches above 200 MB, util.cuh:53 / data.cu:72-98);
 // slice i+2 is copied on the copy stream while steps i and i+1 run.

@@ -552,7 +552,7 @@ class DataProvider {
     std::atomic<bool> _adoptQueued{false};
     void* _evNext = nullptr;      // recorded on the copy stream after the spare slot's upload + tiling
     void* _evSlotFree = nullptr;  // recorded on the compute stream when the batch that used a slot has been fully issued
-    bool _slotFreeRecorded = false;
+    std::atomic<bool> _slotFreeRecorded{false};
     // streamed minibatches (double buffer)
     std::vector<std::unique_ptr<DBuf>> _stream2[2];
     void* _evSliceReady[2] = {nullptr, nullptr};
@@ -561,7 +561,6 @@ class DataProvider {
     bool _sliceFreeRecorded[2] = {false, false};
     void requestSlice(int miniIdx);
    public:
-    void markBatchIssued();  // compute stream: everything reading the current slot has been enqueued
 };
 
 // ---- costs (cost.cu) ------------------------------------------------------------------------
