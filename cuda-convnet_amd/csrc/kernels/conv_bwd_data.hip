@@ -178,6 +178,9 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
                 for (int t = 0; t < NQ * 4; t++) acc[v][t] += red[wave / KS][o][v * NQ * 4 + t][lane];
     }
 
+    // (Requesting this epilogue's operands -- 20 16-byte loads per lane -- BEFORE the k loop, so that they arrive while it runs, was
+    // measured in round 3: 204 VGPRs instead of ~120 cost a wave slot per SIMD; conv2 21.1 -> 24.1 us, local3 15.9 -> 16.8, only
+    // local4's 100 blocks gained, 7.6 -> 6.6.  Left as it is.)
     if constexpr (UNDO) {  // (VECN)
         const int cX = 2 * p.imgX;
 #pragma unroll
