@@ -25,6 +25,7 @@ struct FwdParams {
     int N, imgStride, imgY, imgX, C, F, fs, mY, mX, pad, stride, groups;
     int conv, check, biasPerModule, neuron, mw;
     float sT, sO, na, nb;
+    int xcdPair;  // k_filter_acts, K-split forms: launch order remapped so that a module's two image tiles share an XCD
 };
 
 template <int FV>
@@ -55,9 +56,18 @@ __global__ __launch_bounds__(64 * NW) void k_filter_acts(const FwdParams p) {
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     // KSPLIT: the NW waves of the block share one module and take its k-batches round-robin (summed
     // through LDS below); otherwise each of four waves owns its own module.
-    const int m = KSPLIT ? (int)blockIdx.y : (int)blockIdx.y * 4 + wave;
+    // KSPLIT with two image tiles (N = 128): both blocks of a module read the module's weight slab, the larger operand.  Blocks
+    // go to the eight XCDs round-robin in launch order, so (tile 0, m) and (tile 1, m) -- neighbours in launch order -- sat on
+    // different XCDs and both missed in their L2.  Launch order is remapped in groups of 16: block L of a group works on
+    // module 8 g + L % 8, tile L / 8 -- the two tiles of a module are 8 launches apart, on the SAME XCD.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (KSPLIT && gridDim.x == 2 && p.xcdPair) {
+        const int L = (int)blockIdx.x + 2 * (int)blockIdx.y, g = L >> 4, r = L & 15;
+        if (g * 8 + 8 <= M) { by = g * 8 + (r & 7); bx = r >> 3; }
+    }
+    const int m = KSPLIT ? by : by * 4 + wave;
     if (!KSPLIT && m >= M) return;
-    const int n0 = blockIdx.x * (64 * NQ);
+    const int n0 = bx * (64 * NQ);
     const int f0 = blockIdx.z * (16 * FV);
     const int grp = f0 / fpg;
     const int y0 = p.pad + (m / p.mX) * p.stride, x0 = p.pad + (m % p.mX) * p.stride;
@@ -456,6 +466,8 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
     p.mY = mY; p.mX = mX; p.pad = pad; p.stride = stride; p.groups = groups;
     p.conv = conv; p.biasPerModule = biasPerModule; p.neuron = neuron;
     p.sT = sT; p.sO = sO; p.na = na; p.nb = nb;
+    static const int xcdPairEnv = getenv("MCN_FA_XCD_PAIR") ? atoi(getenv("MCN_FA_XCD_PAIR")) : 1;
+    p.xcdPair = xcdPairEnv;
     const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
     p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY) || (K % 4 != 0);
 
