@@ -49,6 +49,26 @@ struct McnTick {
     int value;
 };
 McnTick mcn_take_tick(hipStream_t stream);  // {nullptr, 0} when nothing is armed for that stream
+
+// Workgroups are dealt to the eight XCDs round-robin in launch order, and every XCD has its own L2: two blocks that are
+// neighbours in launch order NEVER share an L2.  Kernels whose blocks come in groups of T that read the same operands (the tiles
+// of one K chunk, the image tiles of one module, the row / filter tiles of one module chunk) therefore decode their launch index
+// L through this function: the T blocks of a group are spread over 8 T launch slots, 8 apart, so that they land on ONE XCD
+// close together in time.  (Measured with FETCH_SIZE, round 3: fc6's backward-data product 26 -> 13 MB of L2 misses per launch.)
+// The last nG % 8 groups keep the plain group-major order.  Bijective on [0, T * nG).
+__device__ __forceinline__ void mcn_xcd_group(int L, int T, int nG, int& group, int& t) {
+    const int G = 8 * T, full = (nG >> 3) * G;
+    if (L < full) {
+        const int g = L / G, r = L - g * G;
+        group = g * 8 + (r & 7);
+        t = r >> 3;
+    } else {
+        const int l = L - full, q = l / T;
+        group = (nG >> 3) * 8 + q;
+        t = l - q * T;
+    }
+}
+
 #define MCN_TICK_PROLOGUE(p)                                                                          \
     if ((p).tick.flag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && threadIdx.x == 0) {           \
         if ((p).tick.gate) *(volatile int*)(p).tick.gate = (p).tick.value;                            \

@@ -22,6 +22,7 @@ struct BwdWParams {
     int modulesPerChunk, check;
     float sT, sO;
     McnTick tick;  // stored by the launch's first thread (MCN_TICK_PROLOGUE)
+    int xcdGroup;  // k_weight_acts_wide: the row / filter blocks of one module chunk on one XCD (mcn_xcd_group)
 };
 
 // MODE 0: scalar loads (any N / alignment); 1: 16-byte loads through pointers; 2: 16-byte buffer loads -- lanes outside
@@ -48,9 +49,10 @@ __global__ __launch_bounds__(256) void k_weight_acts(BwdWParams p) {
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int kt = blockIdx.y;
-    const int chunk = blockIdx.x;
-    const int f0 = blockIdx.z * (16 * FV);
+    // (mcn_xcd_group -- all blocks of a module chunk on one XCD -- was measured here: no change in L2 misses for conv2, and local3
+    // got slower alone, 13.5 -> 15.8 us, its 18 blocks per module queueing on one XCD; only the wide form below uses it)
+    const int kt = blockIdx.y, chunk = blockIdx.x, ftile = blockIdx.z;
+    const int f0 = ftile * (16 * FV);
     const int grp = f0 / fpg;
     const int kb = kt * 16 * KV;
     const bool check = p.check != 0;
@@ -206,7 +208,14 @@ __global__ __launch_bounds__(256) void k_weight_acts_wide(BwdWParams p) {
     constexpr int FV = 4;
     extern __shared__ int tbl[];
     const int fp = p.fs * p.fs, K = p.C * fp, M = p.mY * p.mX, imgPixels = p.imgY * p.imgX;
-    const int kb0 = blockIdx.y * (32 * KV);
+    int wChunk = blockIdx.x, wKt = blockIdx.y, wFt = blockIdx.z;
+    if (p.xcdGroup) {  // the blocks of a module chunk read the same gradient rows: one XCD per chunk (L2 misses 77 -> 53 MB per launch)
+        int t;
+        mcn_xcd_group((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)(gridDim.y * gridDim.z), (int)gridDim.x, wChunk, t);
+        wFt = t / (int)gridDim.y;
+        wKt = t - wFt * (int)gridDim.y;
+    }
+    const int kb0 = wKt * (32 * KV);
     for (int i = threadIdx.x; i < 32 * KV; i += 256) {
         const int k = kb0 + i, c = k / fp, q = k % fp, fy = q / p.fs, fx = q % p.fs;
         tbl[2 * i] = c * imgPixels + fy * p.imgX + fx;
@@ -215,9 +224,9 @@ __global__ __launch_bounds__(256) void k_weight_acts_wide(BwdWParams p) {
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int chunk = blockIdx.x;
+    const int chunk = wChunk;
     const int kl = (wave & 1) * 16 * KV, kb = kb0 + kl;
-    const int f0 = blockIdx.z * 128 + (wave >> 1) * 64;
+    const int f0 = wFt * 128 + (wave >> 1) * 64;
     const bool check = p.check != 0;
     int off[KV], yx[KV];
 #pragma unroll
@@ -383,6 +392,8 @@ static int weight_acts_launch(const float* images, const float* hidActs, float* 
     p.mY = mY; p.mX = mX; p.pad = pad; p.stride = stride; p.groups = groups;
     p.modulesPerChunk = modulesPerChunk; p.sT = sT; p.sO = sO;
     p.tick = {nullptr, 0};
+    static const int xcdGroupEnv = getenv("MCN_WA_XCD_GROUP") ? atoi(getenv("MCN_WA_XCD_GROUP")) : 1;
+    p.xcdGroup = xcdGroupEnv;
     const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
     p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY);
     const bool vecn = (N % 4 == 0) && (imgStride % 4 == 0) && (((uintptr_t)images | (uintptr_t)hidActs) % 16 == 0);

@@ -263,6 +263,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
+    // (mcn_xcd_group over the image / filter tiles of a module block was measured: conv2+ 29.7 -> 21.9 MB of L2 misses, no change in
+    // time; DeepID2's conv1 / conv2 fetched MORE, 7.9 -> 9.5 MB, and the step lost 0.7 us.  Plain launch order.)
     const int mBeg = (blockIdx.y * 4 + wave) * p.mw, mEnd = min(M, mBeg + p.mw);
     if (mBeg >= M) return;
     const int n0 = blockIdx.x * 64, f0 = blockIdx.z * (16 * FV), grp = f0 / fpg;

@@ -32,6 +32,7 @@ struct FcParams {
     int neuron;
     float alpha, beta, na, nb;
     McnTick tick;    // NN / TN split: stored by the launch's first thread (MCN_TICK_PROLOGUE)
+    int xcdGroup;    // TN split: launch order remapped so that the tiles of a K chunk share an XCD
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -296,8 +297,16 @@ __global__ __launch_bounds__(256) void k_fc_tn_split(const FcParams p) {
     constexpr int H = MG / 4, R = MG % 4, T = MG * 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int mb = blockIdx.y * (16 * MG), nb = blockIdx.x * 64;
-    const int kBeg = blockIdx.z * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
+    // the tiles of one K chunk read the same rows of A and B: one XCD per chunk (mcn_xcd_group; fc6: 37 -> 23 MB per launch)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcdGroup) {
+        int t;
+        mcn_xcd_group((int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)(gridDim.x * gridDim.y), (int)gridDim.z, bz, t);
+        by = t / (int)gridDim.x;
+        bx = t - by * (int)gridDim.x;
+    }
+    const int mb = by * (16 * MG), nb = bx * 64;
+    const int kBeg = bz * p.kChunk, kEnd = min(p.K, kBeg + p.kChunk);
     f32x4 acc[T];
 #pragma unroll
     for (int t = 0; t < T; t++) acc[t] = F4ZERO;
@@ -373,7 +382,7 @@ __global__ __launch_bounds__(256) void k_fc_tn_split(const FcParams p) {
         for (int t = 0; t < T; t++) red[t * 64 + lane] = acc[t];
     }
     __syncthreads();
-    float* slab = p.part + (size_t)blockIdx.z * p.M * p.N;
+    float* slab = p.part + (size_t)bz * p.M * p.N;
     if (!nin) return;
     // tile (mt, t): D row 4kk + r <-> lane-row index jA = 4kk + r of the A operand; column j <-> n = nb + 4j + t
 #pragma unroll
@@ -465,6 +474,7 @@ static FcParams fc_params(const float* A, const float* B, const float* bias, flo
     p.M = M; p.N = N; p.K = K; p.kChunk = K; p.splits = 1;
     p.neuron = neuron; p.alpha = alpha; p.beta = beta; p.na = na; p.nb = nb;
     p.tick = {nullptr, 0};
+    p.xcdGroup = 0;
     return p;
 }
 
@@ -506,6 +516,8 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     p.part = (float*)workspace;
     p.kChunk = pl.kChunk;
     p.splits = pl.splits;
+    static const int xcdGroupEnv = getenv("MCN_TN_XCD_GROUP") ? atoi(getenv("MCN_TN_XCD_GROUP")) : 1;
+    p.xcdGroup = xcdGroupEnv;
     dim3 grid(divup(N, 64), divup(M, 16 * pl.mg), pl.splits);
     MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
     p.tick = mcn_take_tick(s);
@@ -541,6 +553,7 @@ struct FcMultiParams {
     int neuron;
     float fa, fb, fbeta;
     McnTick tick;                 // backward-data: stored by the launch's first thread (MCN_TICK_PROLOGUE)
+    int xcdGroup;                 // forward / backward-data: the column tiles of one row tile on one XCD (mcn_xcd_group)
 };
 
 // ---- forward: Y[M x N] = sum_i W_i X_i (+ bias, neuron).  One workgroup of 8 waves per 16 x 16 tile of Y; the waves split the
@@ -551,7 +564,10 @@ __global__ __launch_bounds__(512) void k_fc_fprop_multi(const FcMultiParams p) {
     __shared__ f32x4 red[4 * 64];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
-    const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+    // the column tiles of a row tile read the same 16 weight rows -- the large operand: one XCD per row tile
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcdGroup) mcn_xcd_group((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, by, bx);
+    const int m0 = by * 16, n0 = bx * 16;
     const int per = (p.totalSteps + 7) / 8;
     const int sBeg = wave * per, sEnd = min(p.totalSteps, sBeg + per);
     const int mrow = min(m0 + j, p.M - 1);
@@ -624,9 +640,11 @@ template <int U>
 __global__ __launch_bounds__(64) void k_fc_bprop_multi(const FcMultiParams p) {
     MCN_TICK_PROLOGUE(p);
     const int lane = threadIdx.x, kk = lane >> 4, j = lane & 15;
-    int seg = 0, tile = blockIdx.y;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcdGroup) mcn_xcd_group((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, by, bx);  // (as in the forward kernel)
+    int seg = 0, tile = by;
     while (tile >= p.steps[seg]) { tile -= p.steps[seg]; seg++; }
-    const int M = p.K[seg], m0 = tile * 32, n0 = blockIdx.x * 32;
+    const int M = p.K[seg], m0 = tile * 32, n0 = bx * 32;
     const float* A = p.A[seg];
     const bool min2 = m0 + 2 * j < M, nin2 = n0 + 2 * j < p.N;  // M, N even
     const float* ab = A + min(m0 + 2 * j, M - 2);
@@ -709,6 +727,8 @@ bool fc_fprop_multi_usable(const float* const* W, const float* const* X, const i
 int fc_fprop_multi_launch(const float* const* W, const float* const* X, const int* K, int count, const float* bias, float* Y, int M,
                           int N, float beta, int neuron, float na, float nb, hipStream_t s) {
     FcMultiParams p = {};
+    static const int fcmXcd = getenv("MCN_FCM_XCD_GROUP") ? atoi(getenv("MCN_FCM_XCD_GROUP")) : 3;  // bit 0: forward, bit 1: backward-data
+    p.xcdGroup = fcmXcd & 1;
     p.nseg = count;
     p.totalSteps = 0;
     for (int i = 0; i < count; i++) {
@@ -739,6 +759,8 @@ bool fc_bprop_multi_usable(const float* const* W, float* const* dX, const int* M
 int fc_bprop_multi_launch(const float* const* W, float* const* dX, const int* Mi, const float* beta, const float* const* nacts,
                           const int* ntype, const float* na, const float* nb, int count, const float* dY, int K, int N, hipStream_t s) {
     FcMultiParams p = {};
+    static const int fcmXcd = getenv("MCN_FCM_XCD_GROUP") ? atoi(getenv("MCN_FCM_XCD_GROUP")) : 3;
+    p.xcdGroup = (fcmXcd >> 1) & 1;
     p.nseg = count;
     int tiles = 0;
     for (int i = 0; i < count; i++) {
