@@ -28,6 +28,7 @@ struct BwdDataParams {
     float uNa, uNb;
     McnTick tick;        // stored by the launch's first thread (MCN_TICK_PROLOGUE)
     int waveCt;          // 1: the four waves of a block are four channel tiles of ONE pixel (they read the same gradient rows)
+    int xcdPair;         // 1: launch order remapped so that the image tiles of a pixel block share an XCD
 };
 
 // A step = one (module, 16 filters) pair.  The steps a pixel needs are walked in batches of U: the loads of the
@@ -53,12 +54,15 @@ __global__ __launch_bounds__(256) void k_img_acts(BwdDataParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform for the compiler: scalar loop control, no exec-masked loops
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
     const bool wct = KS == 1 && p.waveCt;
-    const int pxRaw = wct ? (int)blockIdx.y : blockIdx.y * (4 / KS) + wave / KS, ks = wave % KS;
+    // unshared layers: the image tiles of a pixel block read the same weight rows -- one XCD per pixel block (mcn_xcd_group)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcdPair) mcn_xcd_group((int)(blockIdx.x + gridDim.x * blockIdx.y), (int)gridDim.x, (int)gridDim.y, by, bx);
+    const int pxRaw = wct ? by : by * (4 / KS) + wave / KS, ks = wave % KS;
     const bool live = pxRaw < imgPixels;
     if (KS == 1 && !live) return;  // (with KS == 2 every wave reaches the barrier below)
     const int px = live ? pxRaw : imgPixels - 1;
     const int y = px / p.imgX, x = px % p.imgX;
-    const int n0 = blockIdx.x * (64 * NQ);
+    const int n0 = bx * (64 * NQ);
     const int ctiles = (fc + 16 * CV - 1) / (16 * CV);
     const int zi = wct ? (int)blockIdx.z * 4 + wave : (int)blockIdx.z;
     const int grp = zi / ctiles;
@@ -361,6 +365,8 @@ static int img_acts_impl(const float* hidActs, const float* filters, float* targ
     p.uActs = nullptr; p.uMax = nullptr; p.uTarget = nullptr; p.uNeuron = -1; p.uNa = p.uNb = 0.f;
     p.tick = {nullptr, 0};
     p.waveCt = 0;
+    static const int xcdPairEnv = getenv("MCN_IA_XCD_PAIR") ? atoi(getenv("MCN_IA_XCD_PAIR")) : 1;
+    p.xcdPair = (xcdPairEnv & (conv ? 2 : 1)) != 0 && N > 64;  // bit 0: unshared layers, bit 1: shared-weight layers
     const int fc = C / groups, imgPixels = imgY * imgX;
     const bool vecn = (N % 4 == 0) && (((uintptr_t)hidActs | (uintptr_t)targets) % 16 == 0);
     if (undo) {
