@@ -941,15 +941,20 @@ MCN_API int mcn_softmax_grad(const float* acts, const float* actsGrad, float* ta
 // Pair labels and distances.  The squares are computed by all threads into an LDS tile (independent,
 // coalesced loads); thread j then adds its column of the tile in row order -- the summation order of
 // the reference's SquaredDiff + column-sum and of the CPU oracle.
-__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs, float* sq, int tile) {
-    const int h = numCases / 2;
+// (j0, hw): the window of pairs this block computes -- dists / labs / sq are indexed inside the window; (0, numCases / 2) = all of them
+__device__ void l2sn_stats(const float* idens, const float* data, int numD, int numCases, float* dists, float* labs, float* sq, int tile,
+                           int j0, int hw) {
+    const int hAll = numCases / 2;
+    const int h = hw;
+    idens += j0;
+    data += j0;
     const int TR = max(1, tile / h);
     for (int j = threadIdx.x; j < h; j += blockDim.x) {
-        labs[j] = idens[j] == idens[j + h] ? 1.f : -1.f;
+        labs[j] = idens[j] == idens[j + hAll] ? 1.f : -1.f;
         dists[j] = 0.f;
     }
     // 16-byte loads need h % 4 == 0 (the probe half then starts on a 16-byte boundary too)
-    const bool vec = (h % 4 == 0) && (((uintptr_t)data) % 16 == 0);
+    const bool vec = (h % 4 == 0) && (hAll % 4 == 0) && (((uintptr_t)data) % 16 == 0) && (numCases % 4 == 0);
     const int hq = h / 4;                       // quads per half row
     const int rq = threadIdx.x / max(hq, 1), jq = threadIdx.x % max(hq, 1);  // vector path: (row lane, quad)
     const int RV = max(1, (int)blockDim.x / max(hq, 1));                    // rows per pass
@@ -966,7 +971,7 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
                     if (kk < rows) {
                         const float* g = data + (size_t)(k0 + kk) * numCases + 4 * jq;
                         gv[u] = *reinterpret_cast<const f32x4*>(g);
-                        qv[u] = *reinterpret_cast<const f32x4*>(g + h);
+                        qv[u] = *reinterpret_cast<const f32x4*>(g + hAll);
                     }
                 }
 #pragma unroll
@@ -984,7 +989,7 @@ __device__ void l2sn_stats(const float* idens, const float* data, int numD, int 
             for (int e = threadIdx.x; e < rows * h; e += blockDim.x) {
                 const int kk = e / h, j = e % h;
                 const float* g = data + (size_t)(k0 + kk) * numCases + j;
-                const float d = g[0] - g[h];
+                const float d = g[0] - g[hAll];
                 sq[e] = __fmul_rn(d, d);
             }
         }
@@ -1038,6 +1043,27 @@ __device__ void l2sn_threshold(const float* cd, const float* cl, int cnt, int* r
     }
     __syncthreads();
 }
+// per-pair cost and its sum (one workgroup of 256 threads; layer_kernels.cu:563-604)
+__device__ void l2sn_cost_tail(const float* dists, const float* labs, int h, float m, float* out, double* costOut, double* shsum) {
+    double a = 0;
+    for (int j = threadIdx.x; j < h; j += blockDim.x) {
+        const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
+        const float negMask2 = dists[j] < m ? 1.f : 0.f;
+        const float posLoss = __fmul_rn(__fmul_rn(__fmul_rn(dists[j], dists[j]), 0.5f), posMask);
+        const float t = __fadd_rn(__fmul_rn(-1.0f, dists[j]), m);
+        const float negLoss = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(t, t), 0.5f), negMask1), negMask2);
+        const float o = __fadd_rn(posLoss, negLoss);
+        out[j] = o;
+        a += (double)o;
+    }
+    shsum[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) shsum[threadIdx.x] += shsum[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && costOut) *costOut += shsum[0];
+}
 // MODE 0 cost (one block), 1 grad (block b owns rows [b*rowsPerBlock, ...): every block recomputes the
 // pair statistics and the margin -- 80 KB of L2 reads -- instead of a second launch), 2 stats only.
 template <int MODE>
@@ -1055,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
     float* sq = (float*)(rates + cnt);           // [L2SN_TILE]
     __shared__ float sh_m[2];
     __shared__ double shsum[256];
-    l2sn_stats(idens, data, numD, numCases, dists, labs, sq, tile);
+    l2sn_stats(idens, data, numD, numCases, dists, labs, sq, tile, 0, numCases / 2);
     if (extD) {
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) { cd[i] = extD[i]; cl[i] = extL[i]; }
     }
@@ -1072,24 +1098,7 @@ __global__ __launch_bounds__(256) void k_l2sn(const float* __restrict__ idens, c
     }
     if (info && threadIdx.x == 0 && blockIdx.x == 0) { info[0] = m; info[1] = idx; info[2] = 0.f; info[3] = 0.f; }
     if (MODE == 0) {
-        double a = 0;
-        for (int j = threadIdx.x; j < h; j += blockDim.x) {
-            const float posMask = 0.5f * labs[j] + 0.5f, negMask1 = -0.5f * labs[j] + 0.5f;
-            const float negMask2 = dists[j] < m ? 1.f : 0.f;
-            const float posLoss = __fmul_rn(__fmul_rn(__fmul_rn(dists[j], dists[j]), 0.5f), posMask);
-            const float t = __fadd_rn(__fmul_rn(-1.0f, dists[j]), m);
-            const float negLoss = __fmul_rn(__fmul_rn(__fmul_rn(__fmul_rn(t, t), 0.5f), negMask1), negMask2);
-            const float o = __fadd_rn(posLoss, negLoss);
-            out[j] = o;
-            a += (double)o;
-        }
-        shsum[threadIdx.x] = a;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) shsum[threadIdx.x] += shsum[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0 && costOut) *costOut += shsum[0];
+        l2sn_cost_tail(dists, labs, h, m, out, costOut, shsum);
     } else {
         const int k0 = blockIdx.x * rowsPerBlock, k1 = min(numD, k0 + rowsPerBlock);
         const int rowStep = max(1, (int)blockDim.x / h);
@@ -1170,9 +1179,75 @@ MCN_API int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int n
                        numCases, pairStats, info, add, coeff);
     return MCN_LAUNCH_CHECK("l2snGradFromStats");
 }
+// The pair statistics on several workgroups: block b owns the window of L2SN_WIN pairs [b * L2SN_WIN, ...) -- a pair's squares
+// are still summed by one thread in row order, so every distance keeps its bits -- and writes its part of pairStats.
+#define L2SN_WIN 8
+__global__ __launch_bounds__(256) void k_l2sn_stats_win(const float* __restrict__ idens, const float* __restrict__ data,
+                                                        float* __restrict__ pairStats, int numD, int numCases, int tile) {
+    extern __shared__ float shf[];
+    const int h = numCases / 2, j0 = blockIdx.x * L2SN_WIN, hw = min(L2SN_WIN, h - j0);
+    float* dists = shf;             // [L2SN_WIN]
+    float* labs = shf + L2SN_WIN;   // [L2SN_WIN]
+    float* sq = shf + 2 * L2SN_WIN; // [tile]
+    l2sn_stats(idens, data, numD, numCases, dists, labs, sq, tile, j0, hw);
+    if ((int)threadIdx.x < hw) {
+        pairStats[j0 + threadIdx.x] = dists[threadIdx.x];
+        pairStats[h + j0 + threadIdx.x] = labs[threadIdx.x];
+    }
+}
 MCN_API int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream) {
     MCN_REQUIRE(pairStats, "l2snPairStats: null pointer");
-    return l2sn_launch(2, idens, data, nullptr, numD, numCases, 1.f, 0, 0.f, nullptr, pairStats, nullptr, nullptr, nullptr, 0, stream);
+    MCN_REQUIRE(idens && data && numD > 0 && numCases > 0, "l2snPairStats: bad argument");
+    MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");
+    const int h = numCases / 2;
+    MCN_REQUIRE(h <= L2SN_MAX_PAIRS, "l2sn: too many pairs (%d, limit %d)", h, L2SN_MAX_PAIRS);
+    static const bool oneBlock = getenv("MCN_L2SN_ONE_BLOCK") != nullptr;  // (A/B switch)
+    if (oneBlock || h < 2 * L2SN_WIN)
+        return l2sn_launch(2, idens, data, nullptr, numD, numCases, 1.f, 0, 0.f, nullptr, pairStats, nullptr, nullptr, nullptr, 0, stream);
+    const int tile = L2SN_TILE_MAX;  // floats of squares staged per pass: 1536 rows of a window
+    MCN_LAUNCH(k_l2sn_stats_win, dim3(divup(h, L2SN_WIN)), dim3(256), (2 * L2SN_WIN + tile) * 4, (hipStream_t)stream, idens, data, pairStats,
+               numD, numCases, tile);
+    return MCN_LAUNCH_CHECK("l2snPairStats");
+}
+
+// Margin search and cost from pair statistics that are already in device memory (mcn_l2sn_pair_stats): one small workgroup.
+// Same arithmetic as k_l2sn<0> behind its statistics phase.
+__global__ __launch_bounds__(256) void k_l2sn_cost_stats(const float* __restrict__ pairStats, float* __restrict__ out, int numCases, float m,
+                                                         float* info, double* costOut, const float* extD, const float* extL, int extCount) {
+    extern __shared__ float shf[];
+    const int h = numCases / 2;
+    const int cnt = extD ? extCount : h;
+    float* dists = shf;
+    float* labs = shf + h;
+    float* cd = labs + h;
+    float* cl = cd + (extD ? cnt : 0);
+    int* rates = (int*)(cl + (extD ? cnt : 0));
+    __shared__ float sh_m[2];
+    __shared__ double shsum[256];
+    for (int j = threadIdx.x; j < h; j += blockDim.x) { dists[j] = pairStats[j]; labs[j] = pairStats[h + j]; }
+    if (extD)
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) { cd[i] = extD[i]; cl[i] = extL[i]; }
+    __syncthreads();
+    float idx = -1.f;
+    if (m < 0) {
+        l2sn_threshold(extD ? cd : dists, extD ? cl : labs, cnt, rates, sh_m);
+        m = sh_m[0];
+        idx = sh_m[1];
+    }
+    if (info && threadIdx.x == 0) { info[0] = m; info[1] = idx; info[2] = 0.f; info[3] = 0.f; }
+    l2sn_cost_tail(dists, labs, h, m, out, costOut, shsum);
+}
+MCN_API int mcn_l2sn_cost_from_stats(const float* pairStats, float* output, int numCases, float m, float* info, double* costOut,
+                                     const float* extDists, const float* extLabels, int extCount, void* stream) {
+    MCN_REQUIRE(pairStats && output && numCases > 0, "l2snCostFromStats: bad argument");
+    MCN_REQUIRE(numCases % 2 == 0, "l2sn: numCases must be even");
+    MCN_REQUIRE((extDists == nullptr) == (extLabels == nullptr), "l2sn: extDists and extLabels go together");
+    const int h = numCases / 2, cnt = extDists ? extCount : h;
+    MCN_REQUIRE(h <= L2SN_MAX_PAIRS && cnt <= L2SN_MAX_PAIRS && cnt > 0, "l2sn: too many pairs (%d, limit %d)", cnt, L2SN_MAX_PAIRS);
+    const size_t lds = ((size_t)2 * h + (extDists ? 2 * cnt : 0) + cnt) * 4;
+    MCN_LAUNCH(k_l2sn_cost_stats, dim3(1), dim3(256), lds, (hipStream_t)stream, pairStats, output, numCases, m, info, costOut, extDists,
+               extLabels, extCount);
+    return MCN_LAUNCH_CHECK("l2snCostFromStats");
 }
 
 // ---------------------------------------------------------------- L2 regression (attribute towers)

@@ -1212,7 +1212,7 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
             void* st = _net->stream();  // the exchange stream: statistics, gather, margin search and cost in stream order
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, st), "l2sn pair stats");
             _net->gatherPairsHere(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
-            chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, nullptr, dCost, _gathered.p, _gathered.p + _extCount, _extCount, st), "l2sn cost");
+            chk(mcn_l2sn_cost_from_stats(_pairStats.p, _acts, n, _m, _info.p, dCost, _gathered.p, _gathered.p + _extCount, _extCount, st), "l2sn cost");
             if (cgSeq) _net->signalCommGate(cgSeq);
             else chk(mcn_event_record(_evReady, st), "event record");
         });
@@ -1240,8 +1240,16 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
             _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
             _net->waitGather();
         }
-        chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, gather ? nullptr : _pairStats.p, dCost, gather ? _gathered.p : nullptr,
-                          gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+        // statistics on one workgroup per 8 pairs, then margin search and cost from them on one (round 3; one launch on one
+        // workgroup before: 14 us for 160 features, 35 us for DeepID2+'s 512; MCN_L2SN_ONE_LAUNCH=1 for the A/B)
+        static const bool oneLaunch = getenv("MCN_L2SN_ONE_LAUNCH") != nullptr;
+        if (oneLaunch && !gather) {
+            chk(mcn_l2sn_cost(idens, data, _acts, D, n, _m, _info.p, _pairStats.p, dCost, nullptr, nullptr, 0, _net->stream()), "l2sn cost");
+        } else {
+            if (!gather) chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
+            chk(mcn_l2sn_cost_from_stats(_pairStats.p, _acts, n, _m, _info.p, dCost, gather ? _gathered.p : nullptr,
+                                         gather ? _gathered.p + _extCount : nullptr, _extCount, _net->stream()), "l2sn cost");
+        }
         if (early) chk(mcn_l2sn_grad_from_stats(data, early, D, n, _pairStats.p, _info.p, 0, coeff, _net->stream()), "l2sn grad (early)");
         if (gateSeq) _net->signalGate(gateSeq);
         else chk(timedEventRecord(_evReady, _net->stream()), "event record");

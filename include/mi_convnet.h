@@ -523,8 +523,13 @@ int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarget, int 
  * the margin search (layer.cu:1073-1082 calls computeL2SNGrad with the margin its fprop kept). */
 int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int numD, int numCases, const float* pairStats,
                              const float* info, int add, float coeff, void* stream);
-/* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2] */
+/* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2].  Several workgroups, one per
+ * window of 8 pairs; every distance has the bits mcn_l2sn_cost computes. */
 int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream);
+/* Second half of computeL2SNCost (:563-604, margin search :482-498) from the pair statistics mcn_l2sn_pair_stats left in device
+ * memory: mcn_l2sn_pair_stats + mcn_l2sn_cost_from_stats == mcn_l2sn_cost with pairStats, bit for bit.  Arguments as there. */
+int mcn_l2sn_cost_from_stats(const float* pairStats, float* output, int numCases, float m, float* info, double* costOut,
+                             const float* extDists, const float* extLabels, int extCount, void* stream);
 /* computeFisher2Cost / computeFisher2Grad (layer_kernels.cu:310-369, :371-479; kLabel2Weight :32-47).
  * costOut (device double, may be NULL) += cost * numCases (Fisher2CostLayer::fpropActs layer.cu:1025-1036);
  * dataTarget (numD, numCases) (+)= coeff * gradient.  workspace: mcn_fisher2_workspace_bytes(numCases). */

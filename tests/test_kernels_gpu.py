@@ -754,6 +754,14 @@ def test_l2sn(D, N, m):
         d_t2 = dev(t0)
         call('mcn_l2sn_grad_from_stats', dev(data), d_t2, D, N, d_stats, d_info, add, 0.0025, None)
         assert np.array_equal(d_t2.numpy(), d_t.numpy()), 'gradient from kept statistics must equal the recomputing kernel bit for bit'
+    # the two-launch form the layer graph uses: statistics on one workgroup per 8 pairs, then margin search + cost from them
+    d_stats2 = dev_empty(2 * h, np.nan)
+    call('mcn_l2sn_pair_stats', dev(ids), dev(data), d_stats2, D, N, None)
+    assert np.array_equal(d_stats2.numpy(), stats), 'windowed pair statistics must equal the one-workgroup kernel bit for bit'
+    d_out2, d_info2, d_cost2 = dev_empty((1, h), np.nan), dev_empty(4, np.nan), dev_double(1)
+    call('mcn_l2sn_cost_from_stats', d_stats2, d_out2, N, m, d_info2, d_cost2, None, None, 0, None)
+    assert np.array_equal(d_out2.numpy(), d_out.numpy()) and np.array_equal(d_info2.numpy(), info)
+    assert d_cost2.numpy()[0] == d_cost.numpy()[0]
 
 
 def test_l2sn_external_candidates():
@@ -782,6 +790,9 @@ def test_l2sn_external_candidates():
         info = d_info.numpy()
         assert info[0] == np.float32(wm) and int(info[1]) == widx
         close(d_out.numpy().reshape(-1), wout.reshape(-1)[r * h:(r + 1) * h], rtol=1e-6, what='l2sn cost rank %d' % r)
+        d_out2, d_info2 = dev_empty((1, h), np.nan), dev_empty(4, np.nan)
+        call('mcn_l2sn_cost_from_stats', dev(stats[r]), d_out2, N, -1.0, d_info2, None, dev(ext_d), dev(ext_l), G * h, None)
+        assert np.array_equal(d_out2.numpy(), d_out.numpy()) and np.array_equal(d_info2.numpy(), info)
         d_t = dev_empty((D, N), np.nan)
         call('mcn_l2sn_grad', dev(idss[r]), dev(datas[r]), d_t, D, N, -1.0, 0, 0.0025, dev(ext_d), dev(ext_l), G * h, None)
         got = d_t.numpy()
