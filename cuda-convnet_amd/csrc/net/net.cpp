@@ -19,6 +19,29 @@ void chk(int rc, const char* what) {
 // host time spent in cross-stream synchronisation calls (reported as host.events by runSteps)
 thread_local double g_eventCallMs = 0;
 thread_local double g_blockedMs = 0;
+// MCN_DEBUG_WAITS=1: host time per named wait site (printed when the model is destroyed): where a submitting thread stands still
+static const bool g_debugWaits = getenv("MCN_DEBUG_WAITS") != nullptr;
+static std::mutex g_waitSiteMutex;
+static std::map<std::string, std::pair<double, long>> g_waitSites;
+struct SiteTimer {
+    const char* name;
+    std::chrono::steady_clock::time_point t0;
+    explicit SiteTimer(const char* n) : name(g_debugWaits ? n : nullptr) { if (name) t0 = std::chrono::steady_clock::now(); }
+    ~SiteTimer() {
+        if (!name) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(g_waitSiteMutex);
+        auto& e = g_waitSites[name];
+        e.first += ms;
+        e.second++;
+    }
+};
+static void printWaitSites() {
+    if (!g_debugWaits) return;
+    std::lock_guard<std::mutex> lk(g_waitSiteMutex);
+    for (auto& kv : g_waitSites) fprintf(stderr, "[mcn] wait site %-40s %10.3f ms in %ld calls\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    g_waitSites.clear();
+}
 int timedEventRecord(void* e, void* s) {
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = mcn_event_record(e, s);
@@ -1204,7 +1227,13 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
     _extCount = gather ? h * G : 0;
     if (gather) _gathered.ensure((size_t)2 * h * G);
     float *idens = _inputs[0], *data = _inputs[1];
-    _readyOnExchange = gather && _net->exchangeThreadUsable();
+    // Replicas that own their GPU (stream gates usable): statistics, gather, margin search and cost on the SIDE stream, as on one
+    // GPU -- the side stream is idle until fc6's gradients, the main stream's gate for the result needs no hand-shake between
+    // threads, and the communicator is called by the side thread under the exchange mutex.  (Through the exchange thread the main
+    // thread stood still 57 us per step: 28 waiting for that thread to have recorded its event, 30 inside hipStreamWaitEvent.)
+    static const bool sideGather = getenv("MCN_NO_SIDE_GATHER") == nullptr;
+    const bool gatherOnSide = gather && sideGather && _net->gatesUsable() && pt == PASS_TRAIN;
+    _readyOnExchange = gather && !gatherOnSide && _net->exchangeThreadUsable();
     if (_readyOnExchange) {
         const int cgSeq = _net->commGatesUsable() ? _net->nextCommGateSeq() : 0;
         _readyCommGateSeq = cgSeq;
@@ -1232,10 +1261,13 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
     const float coeff = _coeff;
     // (the seeded form hands _evReady to the layer below, and in a data-parallel run the side thread waits for the exchange
     // stream inside this closure: both keep the event)
-    const int gateSeq = (!early && !gather && _net->gatesUsable()) ? _net->nextGateSeq() : 0;
+    const int gateSeq = (!early && (!gather || gatherOnSide) && _net->gatesUsable()) ? _net->nextGateSeq() : 0;
     _readyGateSeq = gateSeq;
-    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather, early, coeff, gateSeq] {
-        if (gather) {
+    _readyTicket = _net->forkSideWork([this, idens, data, D, n, h, G, gather, gatherOnSide, early, coeff, gateSeq] {
+        if (gatherOnSide) {
+            chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
+            _net->gatherPairsHere(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
+        } else if (gather) {
             chk(mcn_l2sn_pair_stats(idens, data, _pairStats.p, D, n, _net->stream()), "l2sn pair stats");
             _net->allGather2(_pairStats.p, _gathered.p, _pairStats.p + h, _gathered.p + (size_t)h * G, h);
             _net->waitGather();
@@ -1279,6 +1311,7 @@ void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  //
     } else {
         if (_readyOnExchange) _net->waitExchangeSubmitted(_readyTicket);  // that thread has recorded _evReady
         else _net->waitSideSubmitted(_readyTicket);
+        SiteTimer st("l2sn.bprop.streamWait");
         chk(timedStreamWait(_net->stream(), _evReady), "wait event");
     }
     if (_readyOnExchange) _net->exchangeWorkJoined();  // the main stream now follows everything that task issued
@@ -1651,6 +1684,7 @@ ConvNet::~ConvNet() {
     dropStepGraphs();
     _side.stop();
     _commSub.stop();
+    printWaitSites();
     if (getenv("MCN_DEBUG_TIMES") && _rcclCalls) fprintf(stderr, "[mcn] all-reduce calls: %ld, host us per call: %.1f\n", (long)_rcclCalls, _rcclCallNs / 1e3 / _rcclCalls);
     if (_comm) mcn_comm_destroy(_comm);
     if (_commStream) mcn_stream_destroy(_commStream);
@@ -2440,6 +2474,7 @@ long ConvNet::forkExchangeWork(std::function<void()> fn) {
 }
 
 void ConvNet::waitExchangeSubmitted(long ticket) {
+    SiteTimer st("waitExchangeSubmitted");
     if (ticket > 0) _commSub.wait(ticket);
 }
 
@@ -2486,18 +2521,23 @@ void ConvNet::commCollect(std::map<std::string, ProfEntry>& into) {  // worker t
 }
 
 void ConvNet::gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank) {
+    // on the calling thread's stream: the exchange stream (exchange thread) or the side stream (side thread, gated path).  No
+    // lock: only one thread talks to the communicator at a time by construction -- a step's gather is issued before the side
+    // thread hands the step's first bucket to the exchange thread, and after the main thread has seen the previous step's last
+    // exchange issued (waitComm) -- which also makes the order of collectives the same on every rank.
+    void* st = stream();
     void *e0 = nullptr, *e1 = nullptr;
     if (_commTiming) {
         e0 = commEvent();
         e1 = commEvent();
-        chk(mcn_event_record(e0, _commStream), "event record");
+        chk(mcn_event_record(e0, st), "event record");
     }
     chk(mcn_comm_group_begin(), "group begin");
-    chk(mcn_allgather(_comm, sendA, recvA, countPerRank, _commStream), "all-gather");
-    chk(mcn_allgather(_comm, sendB, recvB, countPerRank, _commStream), "all-gather");
+    chk(mcn_allgather(_comm, sendA, recvA, countPerRank, st), "all-gather");
+    chk(mcn_allgather(_comm, sendB, recvB, countPerRank, st), "all-gather");
     chk(mcn_comm_group_end(), "group end");
     if (_commTiming) {
-        chk(mcn_event_record(e1, _commStream), "event record");
+        chk(mcn_event_record(e1, st), "event record");
         _commSpans.push_back({1, e0, e1, 2 * countPerRank});
     }
     logComm(1, 0, countPerRank);
@@ -2506,6 +2546,7 @@ void ConvNet::gatherPairsHere(const float* sendA, float* recvA, const float* sen
 
 void ConvNet::joinExchange() {
     if (!_exchangeWorkPending) return;
+    SiteTimer st("joinExchange");
     _commSub.wait(_commSub.pushed());
     chk(timedEventRecord(_evJoinComm, _commStream), "event record");
     chk(timedStreamWait(_stream, _evJoinComm), "wait event");
@@ -2555,6 +2596,7 @@ void ConvNet::runLateWork() {
 void ConvNet::hostWaitSide() {
     if (!_sideWaitPending) return;
     _sideWaitPending = false;
+    SiteTimer st("hostWaitSide");
     _side.wait(_side.pushed());
 }
 
@@ -2609,7 +2651,10 @@ void ConvNet::joinGradWork(bool deferHostWait, bool keepWeightGate) {
         _gradPending = false;
         static const bool noDefer = getenv("MCN_NO_DEFER_WAIT") != nullptr;  // (A/B switch)
         if (deferHostWait && !dataParallel() && !noDefer) _sideWaitPending = true;
-        else _side.wait(_side.pushed());
+        else {
+            SiteTimer st("joinGradWork.waitSideThread");
+            _side.wait(_side.pushed());
+        }
         return;
     }
     if (!_capturing) {
@@ -2826,7 +2871,11 @@ void ConvNet::flushBuckets(bool force) {
     // every rank.
     static const bool inlineLast = getenv("MCN_NO_INLINE_BUCKET") == nullptr;
     if (force && inlineLast && t_stream == 0 && !_gradPending && !_capturing) {
-        _commSub.wait(_commSub.pushed());
+        {
+            SiteTimer st("flushBuckets.inline.waitExchangeThread");
+            _commSub.wait(_commSub.pushed());
+        }
+        SiteTimer st2("flushBuckets.inline.allreduce_call");
         float* lbuf = _gradArena.p + _sentUpTo;
         const size_t lcount = end - _sentUpTo;
         void *e0 = nullptr, *e1 = nullptr;
@@ -2916,6 +2965,7 @@ void ConvNet::flushBuckets(bool force) {
 }
 
 void ConvNet::waitComm() {
+    SiteTimer st("waitComm");
     std::lock_guard<std::mutex> lk(_commMutex);
     if (_commPending) {
         if (commGatesUsable()) {  // the exchange thread signals behind its last collective; the gate is queued at once

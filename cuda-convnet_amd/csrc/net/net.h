@@ -765,7 +765,7 @@ class ConvNet {
     bool exchangeThreadUsable() const { return _dpOn && _gradStream && !_profiling && _commSub.running(); }
     long forkExchangeWork(std::function<void()> fn);  // on the exchange stream / thread (data parallel)
     void waitExchangeSubmitted(long ticket);
-    void gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // exchange thread only
+    void gatherPairsHere(const float* sendA, float* recvA, const float* sendB, float* recvB, size_t countPerRank);  // exchange or side thread, on its stream
     void joinExchange();
     void exchangeWorkJoined() { _exchangeWorkPending = false; }
     // data-parallel plan, for tests without 8 GPUs: the collectives in the order the exchange thread issued them
