@@ -2107,6 +2107,12 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         chk(mcn_stream_sync(_commStream), "stream sync");
         chk(mcn_allreduce_sum(_comm, _gradArena.p, std::min<size_t>(_gradArena.cap, 8192), _stream), "all-reduce (warm-up)");
         chk(mcn_stream_sync(_stream), "stream sync");
+        if (_gradStream && _gradArena.cap >= (size_t)64 * (world + 1)) {  // (the side stream carries the L2-SN gather of replicas that own their GPU)
+            chk(mcn_comm_group_begin(), "group begin");
+            chk(mcn_allgather(_comm, _gradArena.p, _gradArena.p + 64, 64, _gradStream), "all-gather (warm-up)");
+            chk(mcn_comm_group_end(), "group end");
+            chk(mcn_stream_sync(_gradStream), "stream sync");
+        }
         // replicas wait for each other inside every collective (a peer's first steps page code in): a gate that depends on the
         // exchange stream must outlast that
         if (world > 1) _gateTimeoutMs = 120000;
