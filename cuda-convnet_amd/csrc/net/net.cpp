@@ -2907,6 +2907,33 @@ void ConvNet::flushBuckets(bool force) {
             onMain |= sg.onMain;
             onSide |= sg.onSide;
         }
+    // An exchange stream that shares a hardware queue with a compute stream (the start-up self-test: no comm gates) buys no
+    // overlap over the side stream itself -- the runtime puts it on the side stream's queue -- but costs an event record, a
+    // hop to the exchange thread, a queued wait there (10-15 us on that queue) and another queued wait on the main stream
+    // before the update.  A bucket written by the side stream alone is then exchanged IN LINE on the side stream by the side
+    // thread: stream order is the dependency, and the join the main stream makes anyway covers the exchange.
+    static const bool sideExchange = getenv("MCN_NO_SIDE_EXCHANGE") == nullptr;
+    if (sideExchange && !force && t_stream == 1 && !onMain && !commGatesUsable() && gatesUsable() && !_capturing && !_commTicks) {
+        float* sbuf = _gradArena.p + _sentUpTo;
+        const size_t scount = end - _sentUpTo;
+        void *e0 = nullptr, *e1 = nullptr;
+        if (_commTiming) {
+            e0 = commEvent();
+            e1 = commEvent();
+            chk(mcn_event_record(e0, _gradStream), "event record");
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        chk(mcn_allreduce_sum(_comm, sbuf, scount, _gradStream), "all-reduce (side stream)");
+        _rcclCallNs += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        _rcclCalls++;
+        if (_commTiming) {
+            chk(mcn_event_record(e1, _gradStream), "event record");
+            _commSpans.push_back({0, e0, e1, scount});
+        }
+        logComm(0, _sentUpTo, scount);
+        _sentUpTo = end;
+        return;
+    }
     // the producer records (cheap), the exchange thread waits and calls RCCL (expensive)
     void* evMain = nullptr;
     void* evSide = nullptr;
