@@ -2070,7 +2070,10 @@ void ConvNet::initComm(int rank, int world, const char* id128, bool force) {
         // gate of one rank would spin on the device its peer needs to get there.  Spinning is for ranks that own their GPU.
         if (!isRccl && world > 1) _gateOk = _forkGateOk = false;
         chk(mcn_stream_create(&_commStream), "comm stream");
-        if (_gateOk && _gradStream && getenv("MCN_NO_COMM_GATES") == nullptr) {
+        // Opt-in (MCN_COMM_GATES=1): on every box of the pool the exchange stream shares a hardware queue, the self-test below
+        // says so, and the gated exchange path has therefore never run on hardware with more than the self-test behind it.  The
+        // default is what HAS run: side-stream buckets exchanged in line on the side stream (flushBuckets), events elsewhere.
+        if (_gateOk && _gradStream && getenv("MCN_COMM_GATES") != nullptr && getenv("MCN_NO_COMM_GATES") == nullptr) {
             chk(mcn_gate_alloc(&_commGate), "gate");
             chk(mcn_gate_alloc(&_mainToComm), "gate");
             chk(mcn_gate_alloc(&_sideToComm), "gate");
