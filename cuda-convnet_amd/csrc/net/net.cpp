@@ -1229,7 +1229,7 @@ void L2SNCostLayer::fpropActs(int i, float, PassType pt) {  // layer.cu:1060-107
     float *idens = _inputs[0], *data = _inputs[1];
     // Replicas that own their GPU (stream gates usable): statistics, gather, margin search and cost on the SIDE stream, as on one
     // GPU -- the side stream is idle until fc6's gradients, the main stream's gate for the result needs no hand-shake between
-    // threads, and the communicator is called by the side thread under the exchange mutex.  (Through the exchange thread the main
+    // threads, and the communicator is called by the side thread (never at the same time as another thread: gatherPairsHere).  (Through the exchange thread the main
     // thread stood still 57 us per step: 28 waiting for that thread to have recorded its event, 30 inside hipStreamWaitEvent.)
     static const bool sideGather = getenv("MCN_NO_SIDE_GATHER") == nullptr;
     const bool gatherOnSide = gather && sideGather && _net->gatesUsable() && pt == PASS_TRAIN;
