@@ -26,6 +26,7 @@ struct FwdParams {
     int conv, check, biasPerModule, neuron, mw;
     float sT, sO, na, nb;
     int xcdPair;  // k_filter_acts, K-split forms: launch order remapped so that a module's two image tiles share an XCD
+    float* pool;  // k_conv_fwd_fast<.., POOL>: (F, mY/2, mX/2, N) max over the 2 x 2 module quads, written by the same launch
 };
 
 template <int FV>
@@ -243,7 +244,15 @@ __device__ __forceinline__ AVec<FV> buf_load_avec(__amdgpu_buffer_rsrc_t r, unsi
     return a;
 }
 
-template <int FV, int UB, bool CHECK, bool RELU>
+//
+// POOL: the launch also writes the 2 x 2 / stride 2 max pool of its output (MaxPooler of conv_util.cuh through convLocalPool,
+// conv_util.cu; PoolLayer::fpropActs layer.cu:718-726), which otherwise is a launch of its own that reads the whole conv output
+// again.  Modules are then numbered in quad order -- index g <-> quad g >> 2 (row-major over the (mY/2, mX/2) pooled map),
+// corner g & 3 -- so that a strip of mw = 4 or 8 modules is one or two whole quads of ONE wave (running maximum in registers),
+// and with mw = 1 or 2 the 4 / mw waves that share a quad sit in the same workgroup and combine through LDS after their strips.
+// The conv output itself is stored as before (the backward pass needs it); max is exact, so both outputs are bitwise those of the
+// two separate launches.
+template <int FV, int UB, bool CHECK, bool RELU, bool POOL = false>
 __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
     extern __shared__ int tbl[];
     constexpr int KB = 4 * UB;
@@ -260,6 +269,8 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
             tbl[2 * k + 1] = 0;
         }
     }
+    int* arrived = tbl + 2 * Kpad + (p.mw == 2 ? 8 : 4) * FV * 4 * 64 * 4;  // POOL: per quad of this workgroup, how many of its waves have finished
+    if (POOL && threadIdx.x < 4) arrived[threadIdx.x] = 0;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, kk = lane >> 4, j = lane & 15;
@@ -299,8 +310,43 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
     AVec<FV> a0[UB], a1[UB];
     f32x4 b0[UB], b1[UB];
     // load cursor (module, batch) and compute cursor; module coordinates are wave-uniform
-    int lm = mBeg, lb = 0, lmy = mBeg / p.mX, lmx = mBeg % p.mX;
-    int cm = mBeg, cb = 0;
+    int lm = mBeg, lb = 0, lmy, lmx;
+    int cm = mBeg, cb = 0, cmy, cmx;
+    const int qX = p.mX >> 1;
+    if (POOL) {
+        const int quad = mBeg >> 2, sub = mBeg & 3;
+        lmy = 2 * (quad / qX) + (sub >> 1);
+        lmx = 2 * (quad % qX) + (sub & 1);
+    } else {
+        lmy = mBeg / p.mX;
+        lmx = mBeg % p.mX;
+    }
+    cmy = lmy;
+    cmx = lmx;
+    // next module of the walk: row-major, or the corners of a quad and then the quad to the right / the first of the next quad row
+    // (plain value arithmetic: with branches that update my OR mx the compiler selected between their ADDRESSES and moved the
+    // cursors to scratch memory)
+    auto advance = [&](int& g, int& my, int& mx) {
+        g++;
+        int nx, ny;
+        if (POOL) {
+            const int sub = g & 3;
+            nx = mx + (sub == 2 ? -1 : 1);
+            ny = my + (sub == 2 ? 1 : (sub == 0 ? -1 : 0));
+            const bool wrap = sub == 0 && nx == p.mX;
+            ny = wrap ? ny + 2 : ny;
+            nx = wrap ? 0 : nx;
+        } else {
+            const bool wrap = mx + 1 == p.mX;
+            nx = wrap ? 0 : mx + 1;
+            ny = wrap ? my + 1 : my;
+        }
+        mx = nx;
+        my = ny;
+    };
+    // POOL: per-module maxima go through LDS slot sets of FV * 4 entries (filter rows) x 64 lanes (in registers they would cost
+    // 16 FV VGPRs across the whole k loop: conv1+ dropped from two waves per SIMD to one)
+    f32x4* ex = reinterpret_cast<f32x4*>(tbl + 2 * Kpad) + lane;
     auto load = [&](AVec<FV>(&a)[UB], f32x4(&b)[UB]) {
         const int y0 = p.pad + lmy * p.stride, x0 = p.pad + lmx * p.stride;
         const int modBase = (y0 * p.imgX + x0) * p.imgStride * 4;  // may be negative with padding (CHECK)
@@ -321,8 +367,7 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
         }
         if (++lb == nb) {
             lb = 0;
-            lm++;
-            if (++lmx == p.mX) { lmx = 0; lmy++; }
+            advance(lm, lmy, lmx);
         }
     };
     auto compute = [&](const AVec<FV>(&a)[UB], const f32x4(&b)[UB]) {
@@ -348,7 +393,14 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
             // module finished: bias, neuron, store (D row 4kk+r of MFMA u <-> filter f0+FV*(4kk+r)+u; col j, MFMA t <-> image n+t)
             // plain global stores (uniform module base + the lane's 32-bit offset): with buffer stores hipcc 7.2
             // reused the data registers in the very next VALU instruction and the last lanes stored the next row
-            char* mbase = reinterpret_cast<char*>(p.targets + (size_t)cm * p.N);
+            char* mbase = reinterpret_cast<char*>(p.targets + (size_t)(POOL ? cmy * p.mX + cmx : cm) * p.N);
+            // POOL (all wave-uniform): strips of 4 / 8 modules keep the running maximum of the quad in the wave's slot set and store
+            // the pooled rows with the quad's last module; strips of 1 / 2 modules write one slot set per module, no read-back
+            const bool quadDone = POOL && p.mw >= 4 && (cm & 3) == 3;
+            const bool rmw = POOL && p.mw >= 4 && (cm & 3) != 0;
+            const int setBase = POOL ? (p.mw >= 4 ? wave : wave * p.mw + (cm - mBeg)) * (FV * 4) : 0;
+            char* pbase = POOL ? reinterpret_cast<char*>(p.pool + (size_t)(cm >> 2) * p.N) : nullptr;
+            const unsigned n4 = (unsigned)n * 4u;
             if (n < p.N) {
 #pragma unroll
                 for (int u = 0; u < FV; u++)
@@ -364,30 +416,78 @@ __global__ __launch_bounds__(256) void k_conv_fwd_fast(const FwdParams p) {
                         f32x4* dst = reinterpret_cast<f32x4*>(mbase + outOff[u][r]);
                         if (p.sT != 0.f) v += p.sT * *dst;
                         *dst = v;
+                        if (POOL) {
+                            f32x4* slot = ex + (setBase + u * 4 + r) * 64;
+                            if (rmw) {
+                                const f32x4 o = *slot;
+#pragma unroll
+                                for (int t = 0; t < 4; t++) v[t] = fmaxf(v[t], o[t]);
+                            }
+                            // (pooled map: M / 4 entries per filter -- the lane's offset follows from the conv output's)
+                            if (quadDone) *reinterpret_cast<f32x4*>(pbase + (((outOff[u][r] - n4) >> 2) + n4)) = v;
+                            else *slot = v;
+                        }
                     }
             }
             cb = 0;
-            cm++;
+            advance(cm, cmy, cmx);
         }
     };
-    load(a0, b0);
-    // (the explicit one-batch-in-flight loop of k_weight_acts_wide -- unconditional loads, s_waitcnt vmcnt(0) before each issue --
-    // was measured here too: conv1 12.6 -> 14.6 us, conv2 14.4 -> 15.8, DeepID2+ conv2 unchanged; the compiler's step-by-step
-    // waits inside a batch are worth more than the overlap between batches)
-    while (true) {
-        if (lm < mEnd) load(a1, b1);
-        compute(a0, b0);
-        if (cm >= mEnd) break;
-        if (lm < mEnd) load(a0, b0);
-        compute(a1, b1);
-        if (cm >= mEnd) break;
+    {
+        load(a0, b0);
+        // (the explicit one-batch-in-flight loop of k_weight_acts_wide -- unconditional loads, s_waitcnt vmcnt(0) before each issue --
+        // was measured here too: conv1 12.6 -> 14.6 us, conv2 14.4 -> 15.8, DeepID2+ conv2 unchanged; the compiler's step-by-step
+        // waits inside a batch are worth more than the overlap between batches)
+        while (true) {
+            if (lm < mEnd) load(a1, b1);
+            compute(a0, b0);
+            if (cm >= mEnd) break;
+            if (lm < mEnd) load(a0, b0);
+            compute(a1, b1);
+            if (cm >= mEnd) break;
+        }
+    }
+    if constexpr (POOL) {
+        if (p.mw >= 4) return;
+        // mw = 1 / 2: the 4 / mw waves of a quad (consecutive waves of this workgroup: strips are aligned) have left the quad's four
+        // modules in four consecutive slot sets, and whichever of them finishes LAST takes their maximum and stores the pooled rows.
+        // (A barrier instead keeps every wave of the workgroup resident until the slowest one arrives, and conv1+ ran 5 us longer.)
+        // LDS instructions execute in issue order, so a wave's slot writes are complete before its counter increment is.
+        const int q = p.mw == 1 ? 0 : wave >> 1;  // which quad of this workgroup
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int before = 0;
+        if (lane == 0) before = __hip_atomic_fetch_add(arrived + q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        before = __builtin_amdgcn_readfirstlane(before);
+        asm volatile("" ::: "memory");
+        if (before != 4 / p.mw - 1 || n >= p.N) return;
+        const f32x4* sets = ex + q * 4 * (FV * 4) * 64;
+        char* pbase = reinterpret_cast<char*>(p.pool + (size_t)(mBeg >> 2) * p.N);
+        const unsigned n4 = (unsigned)n * 4u;
+#pragma unroll
+        for (int u = 0; u < FV; u++) {
+            f32x4 c[4][4];  // every read of the component in flight before the first maximum
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) c[r][g] = sets[(g * (FV * 4) + u * 4 + r) * 64];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                f32x4 m4;
+#pragma unroll
+                for (int t = 0; t < 4; t++) m4[t] = fmaxf(fmaxf(c[r][0][t], c[r][1][t]), fmaxf(c[r][2][t], c[r][3][t]));
+                *reinterpret_cast<f32x4*>(pbase + (((outOff[u][r] - n4) >> 2) + n4)) = m4;
+            }
+        }
     }
 }
 
 template <int FV, int UB>
 static void launch_fast2(const FwdParams& p, dim3 grid, size_t lds, hipStream_t s) {
     const bool relu = p.neuron == MCN_NEURON_RELU;
-    if (p.check) {
+    if (p.pool) {  // (never with check: the host takes this form only when the modules tile the image exactly)
+        if (relu) MCN_LAUNCH((k_conv_fwd_fast<FV, UB, false, true, true>), grid, dim3(256), lds, s, p);
+        else MCN_LAUNCH((k_conv_fwd_fast<FV, UB, false, false, true>), grid, dim3(256), lds, s, p);
+    } else if (p.check) {
         if (relu) MCN_LAUNCH((k_conv_fwd_fast<FV, UB, true, true>), grid, dim3(256), lds, s, p);
         else MCN_LAUNCH((k_conv_fwd_fast<FV, UB, true, false>), grid, dim3(256), lds, s, p);
     } else {
@@ -446,7 +546,7 @@ static void launch_fwd1(const FwdParams& p, int nq, int U, dim3 grid, size_t lds
 static int filter_acts_impl(const float* images, const float* filters, const float* biases, float* targets,
                             int N, int imgStride, int imgY, int imgX, int C, int F, int fs, int mY, int mX,
                             int pad, int stride, int groups, int conv, float sT, float sO, int biasPerModule,
-                            int neuron, float na, float nb, void* stream) {
+                            int neuron, float na, float nb, void* stream, float* pool = nullptr, bool probe = false) {
     // host asserts of _filterActs (filter_acts.cu:577-614), reported instead of aborting
     MCN_REQUIRE(images && filters && targets, "filterActs: null pointer");
     MCN_REQUIRE(N > 0 && imgY > 0 && imgX > 0 && C > 0 && F > 0 && fs > 0 && mY > 0 && mX > 0 && stride > 0 && groups > 0,
@@ -470,6 +570,7 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
     p.sT = sT; p.sO = sO; p.na = na; p.nb = nb;
     static const int xcdPairEnv = getenv("MCN_FA_XCD_PAIR") ? atoi(getenv("MCN_FA_XCD_PAIR")) : 1;
     p.xcdPair = xcdPairEnv;
+    p.pool = nullptr;
     const int fc = C / groups, K = fc * fs * fs, M = mY * mX, fpg = F / groups;
     p.check = (pad < 0) || (pad + (mX - 1) * stride + fs > imgX) || (pad + (mY - 1) * stride + fs > imgY) || (K % 4 != 0);
 
@@ -487,12 +588,23 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
             if (ftiles % fv == 0 && (long)ntiles * M * (F / (16 * fv)) >= 2048) { FV = fv; break; }
         const long waves1 = (long)ntiles * M * (F / (16 * FV));
         p.mw = (int)std::max<long>(1, std::min<long>(8, waves1 / 2560));
+        if (pool || probe) {  // the fused 2 x 2 max pool: whole quads, strips of 1, 2, 4 or 8 modules in quad order
+            if (p.check || (mY & 1) || (mX & 1) || sT != 0.f) {
+                if (probe) return 0;
+                MCN_REQUIRE(false, "filterActs + pool: the modules must tile the image exactly in an even number of rows and columns");
+            }
+            if (probe) return 1;
+            p.pool = pool;
+            p.mw = p.mw >= 8 ? 8 : p.mw >= 4 ? 4 : p.mw;
+            if (p.mw == 3) p.mw = 2;
+        }
         const int S = divup(K, 4);
         const int UB = (FV <= 2 && S % 12 == 0) ? 12 : (FV == 4 ? 6 : (FV == 1 ? 16 : 8));
         dim3 grid(ntiles, divup(divup(M, p.mw), 4), F / (16 * FV));
         MCN_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "filterActs: grid too large");
-        const size_t lds = (size_t)divup(K, 4 * UB) * 4 * UB * 8;
-        MCN_REQUIRE(lds <= 64 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
+        size_t lds = (size_t)divup(K, 4 * UB) * 4 * UB * 8;
+        if (p.pool) lds += (size_t)(p.mw == 2 ? 8 : 4) * FV * 4 * 64 * 16 + 16;  // one slot set per module of the block's quads (per wave for whole-quad strips) + the arrival counters
+        MCN_REQUIRE(lds <= 136 * 1024, "filterActs: filter too large for the decode table (%zu bytes)", lds);
         hipStream_t s = (hipStream_t)stream;
         if (FV == 4) launch_fast2<4, 6>(p, grid, lds, s);
         else if (FV == 3) launch_fast2<3, 8>(p, grid, lds, s);
@@ -502,6 +614,8 @@ static int filter_acts_impl(const float* images, const float* filters, const flo
         else launch_fast2<1, 16>(p, grid, lds, s);
         return MCN_LAUNCH_CHECK("filterActs");
     }
+    if (probe) return 0;
+    MCN_REQUIRE(!pool, "filterActs + pool: shape outside the fused form (mcn_filter_acts_pool_supported)");
     auto best_fv = [&](int cap) {
         for (int fv = cap; fv > 1; fv--)
             if (ftiles % fv == 0) return fv;
@@ -581,4 +695,30 @@ MCN_API int mcn_filter_acts_bias_neuron(const float* images, const float* filter
     return filter_acts_impl(images, filters, biases, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
                             numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups,
                             conv ? 1 : 0, 0.f, 1.f, biasPerModule, neuron, neuronA, neuronB, stream);
+}
+
+// filterActs + bias + neuron + the 2 x 2 / stride 2 / start 0 max pool of the result in one launch (shared-weight conv layers whose
+// modules tile the image; ConvLayer::fpropActs layer.cu:443-462 followed by PoolLayer::fpropActs layer.cu:718-726).  targets gets
+// the (numFilters, modules, numImages) conv output, poolTargets the (numFilters, numModulesY/2, numModulesX/2, numImages) maxima.
+MCN_API int mcn_filter_acts_pool_supported(const float* images, const float* filters, const float* biases, const float* targets,
+                                           int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                           int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                           int numGroups, int conv, int biasPerModule, int neuron) {
+    if (!images || !filters || !targets || numImages <= 0 || numGroups <= 0 || numImgColors % numGroups != 0 ||
+        numFilters % (16 * numGroups) != 0 || !neuron_valid(neuron))
+        return 0;
+    return filter_acts_impl(images, filters, biases, const_cast<float*>(targets), numImages, imgStride, imgSizeY, imgSizeX, numImgColors,
+                            numFilters, filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups, conv ? 1 : 0, 0.f,
+                            1.f, biasPerModule, neuron, 0.f, 0.f, nullptr, nullptr, true) == 1 ? 1 : 0;
+}
+
+MCN_API int mcn_filter_acts_bias_neuron_pool(const float* images, const float* filters, const float* biases, float* targets,
+                                             float* poolTargets, int numImages, int imgStride, int imgSizeY, int imgSizeX,
+                                             int numImgColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                             int paddingStart, int moduleStride, int numGroups, int conv, int biasPerModule, int neuron,
+                                             float neuronA, float neuronB, void* stream) {
+    MCN_REQUIRE(poolTargets && ((uintptr_t)poolTargets % 16) == 0, "filterActs + pool: pool target missing or not 16-byte aligned");
+    return filter_acts_impl(images, filters, biases, targets, numImages, imgStride, imgSizeY, imgSizeX, numImgColors, numFilters,
+                            filterSize, numModulesY, numModulesX, paddingStart, moduleStride, numGroups, conv ? 1 : 0, 0.f, 1.f,
+                            biasPerModule, neuron, neuronA, neuronB, stream, poolTargets, false);
 }

@@ -749,6 +749,19 @@ void LocalLayer::fpropActs(int i, float scaleTargets, PassType) {  // layer.cu:4
     }
     if (scaleTargets == 0) {
         const bool fuse = fusedNeuron && _prev.size() == 1;
+        const int biasPerModule = (_conv && _sharedBiases) ? 0 : 1, ntype = fuse ? fusedNeuron->spec.type : MCN_NEURON_IDENT;
+        float* pooled = fusedPool && _prev.size() == 1 ? fusedPool->ownActs() : nullptr;
+        if (pooled && mcn_filter_acts_pool_supported(in, _weights[i]->W(), _biases->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i],
+                                                     channels, _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
+                                                     (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, biasPerModule, ntype) == 1) {
+            chk(mcn_filter_acts_bias_neuron_pool(in, _weights[i]->W(), _biases->W(), _acts, pooled, n, n, (int)_imgSizeY[i],
+                                                 (int)_imgSizeX[i], channels, _filters, (int)_filterSize[i], _modulesY, _modulesX,
+                                                 (int)_padding[i], (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, biasPerModule, ntype,
+                                                 fuse ? fusedNeuron->spec.a : 0.f, fuse ? fusedNeuron->spec.b : 0.f, _net->stream()),
+                "filterActs + pool");
+            fusedPool->fwdDoneBelow = true;
+            return;
+        }
         chk(mcn_filter_acts_bias_neuron(in, _weights[i]->W(), _biases->W(), _acts, n, n, (int)_imgSizeY[i], (int)_imgSizeX[i],
                                         channels, _filters, (int)_filterSize[i], _modulesY, _modulesX, (int)_padding[i],
                                         (int)_stride[i], (int)_groups[i], _conv ? 1 : 0, (_conv && _sharedBiases) ? 0 : 1,
@@ -957,7 +970,16 @@ PoolLayer::PoolLayer(ConvNet* net, const Params& p) : Layer(net, p) {
     _max = pool == "max";
 }
 
+bool PoolLayer::quadFusable(int filters, int modulesY, int modulesX) const {
+    return _max && _actsTarget < 0 && _channels == filters && _imgSizeY == modulesY && _imgSizeX == modulesX && _sizeX == 2 && _stride == 2 &&
+           _start == 0 && modulesY % 2 == 0 && modulesX % 2 == 0 && _outputsY == modulesY / 2 && _outputsX == modulesX / 2;
+}
+
 void PoolLayer::fpropActs(int, float, PassType) {
+    if (fwdDoneBelow) {  // the conv layer's forward launch wrote this pool's output
+        fwdDoneBelow = false;
+        return;
+    }
     chk(mcn_local_pool(_inputs[0], _acts, _net->numCases(), _channels, _imgSizeY, _imgSizeX, _sizeX, _start, _stride, _outputsY, _outputsX,
                        _max ? 0 : 1, _net->stream()), "pool");
 }
@@ -1729,6 +1751,20 @@ void ConvNet::buildFusions() {
                     r->fwdFused = true;
                 }
             }
+        }
+        // conv layer (one input) whose output -- through the fused neuron, if any -- feeds a 2 x 2 / stride 2 max pool that tiles
+        // the maps: the pool's output comes out of the forward launch too (MCN_NO_POOL_FUSION=1: as separate launches)
+        if (auto* cl = dynamic_cast<LocalLayer*>(up.get())) {
+            const bool off = getenv("MCN_NO_POOL_FUSION") != nullptr;  // (read per model: tests toggle it in one process)
+            Layer* out = cl->fusedNeuron ? static_cast<Layer*>(cl->fusedNeuron) : static_cast<Layer*>(cl);
+            if (!off && cl->isConv() && cl->prev().size() == 1)
+                for (Layer* l : out->next()) {
+                    auto* pl = dynamic_cast<PoolLayer*>(l);
+                    if (pl && pl->prev().size() == 1 && pl->quadFusable(cl->filters(), cl->modulesY(), cl->modulesX())) {
+                        cl->fusedPool = pl;
+                        break;
+                    }
+                }
         }
         // FC layer with several inputs: all of them in one launch per direction; the forward neuron and, per input, the
         // gradient of a neuron layer feeding only this layer go into the epilogues

@@ -245,6 +245,11 @@ class LocalLayer : public WeightLayer {
     LocalLayer(ConvNet* net, const Params& p, bool useGrad, bool conv);
     size_t workspaceBytes(int maxCases) override;
     bool planFusedTail(int numCases) override;
+    class PoolLayer* fusedPool = nullptr;  // max pool over this layer's (neuron's) output written by the forward launch itself
+    bool isConv() const { return _conv; }
+    int filters() const { return _filters; }
+    int modulesY() const { return _modulesY; }
+    int modulesX() const { return _modulesX; }
    protected:
     std::vector<std::unique_ptr<DBuf>> _wgradParts;  // conv: module-chunk partials of each weight gradient (fused update)
     std::vector<int> _wgradChunks;
@@ -326,7 +331,12 @@ class PoolLayer : public Layer {
     // last of the pool's consumers to report: undoFusable = the windows tile the maps, this pool alone feeds the layer below
     bool undoFusable(int numCases, int channels, int outY, int outX) const;
     bool undoDoneAbove = false;  // ... for the pass in flight: bpropActs has nothing left to do
-    void resetPassFlags() override { undoDoneAbove = false; }
+    // the conv layer below (through its fused neuron) may write this pool's output in its own launch (mcn_filter_acts_bias_neuron_pool):
+    // quadFusable = max over the 2 x 2 / stride 2 / start 0 windows that tile a (modulesY, modulesX) map of `filters` channels
+    bool quadFusable(int filters, int modulesY, int modulesX) const;
+    float* ownActs() { return _actsTarget < 0 ? _ownActs.p : nullptr; }
+    bool fwdDoneBelow = false;   // ... for the pass in flight: fpropActs has nothing left to do
+    void resetPassFlags() override { undoDoneAbove = false; fwdDoneBelow = false; }
    protected:
     void fpropActs(int, float, PassType) override;
     void bpropActs(float* v, int, float, PassType) override;

@@ -156,6 +156,19 @@ int mcn_filter_acts_bias_neuron(const float* images, const float* filters, const
                                 int numFilters, int filterSize, int numModulesY, int numModulesX,
                                 int paddingStart, int moduleStride, int numGroups, int conv,
                                 int biasPerModule, int neuron, float neuronA, float neuronB, void* stream);
+/* The same launch also writing the max pool that follows the layer (PoolLayer::fpropActs layer.cu:718-726 = convLocalPool with
+ * MaxPooler, conv_util.cuh, for sizeX 2, stride 2, start 0): targets as above, poolTargets (numFilters*(numModulesY/2)*(numModulesX/2),
+ * numImages).  Shared-weight conv layers whose modules tile the image exactly in an even number of rows and columns
+ * (mcn_filter_acts_pool_supported = 1); both outputs are bitwise those of mcn_filter_acts_bias_neuron + mcn_local_pool. */
+int mcn_filter_acts_pool_supported(const float* images, const float* filters, const float* biases, const float* targets,
+                                   int numImages, int imgStride, int imgSizeY, int imgSizeX, int numImgColors, int numFilters,
+                                   int filterSize, int numModulesY, int numModulesX, int paddingStart, int moduleStride,
+                                   int numGroups, int conv, int biasPerModule, int neuron);
+int mcn_filter_acts_bias_neuron_pool(const float* images, const float* filters, const float* biases, float* targets,
+                                     float* poolTargets, int numImages, int imgStride, int imgSizeY, int imgSizeX,
+                                     int numImgColors, int numFilters, int filterSize, int numModulesY, int numModulesX,
+                                     int paddingStart, int moduleStride, int numGroups, int conv, int biasPerModule, int neuron,
+                                     float neuronA, float neuronB, void* stream);
 
 /* convImgActs (cudaconv2.cuh:54-56, img_acts.cu:1892-1900) / localImgActs (:60-62, :1904-1912).
  * hidActs (numFilters*modules, numImages) -> targets (numImgColors*imgSizeY*imgSizeX, numImages). */

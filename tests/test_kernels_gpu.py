@@ -131,6 +131,51 @@ def test_filter_acts_bias_neuron(name, per_module):
     close(d_out.numpy(), want, what=name)
 
 
+# the forward launch that also writes the 2 x 2 max pool of its output: strips of 1, 2, 4 and 8 modules (quads shared by 4 / 2 / 1
+# waves), filter vectors of 1-4 tiles, ragged image tiles
+@pytest.mark.parametrize('name,N', [('conv2', 128), ('conv1_55', 128), ('conv1_55', 256), ('conv1_55', 512), ('conv1_plus', 128),
+                                    ('conv2_plus', 128), ('conv_f48', 448), ('conv2_39x31', 100), ('conv1_39x31', 4), ('conv2', 96)])
+@pytest.mark.parametrize('neuron', [1, 0])
+def test_filter_acts_with_the_max_pool_in_the_same_launch(name, N, neuron):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    rng = np.random.default_rng(41)
+    img = mk(rng, C_ * imgY * imgX, N)
+    W = mk(rng, *filt_shape(g), scale=0.04)
+    b = mk(rng, F, scale=0.1)
+    d_img, d_W, d_b = dev(img), dev(W), dev(b)
+    shape_args = (N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, 1, 0, neuron)
+    d_ref = dev_empty((F * mY * mX, N), np.nan)
+    call('mcn_filter_acts_bias_neuron', d_img, d_W, d_b, d_ref, *shape_args, 0.0, 0.0, None)
+    d_pref = dev_empty((F * (mY // 2) * (mX // 2), N), np.nan)
+    call('mcn_local_pool', d_ref, d_pref, N, F, mY, mX, 2, 0, 2, mY // 2, mX // 2, 0, None)
+    assert capi.lib().raw('mcn_filter_acts_pool_supported')(d_img.ptr, d_W.ptr, d_b.ptr, d_ref.ptr, *shape_args) == 1
+    d_out, d_pool = dev_empty((F * mY * mX, N), np.nan), dev_empty((F * (mY // 2) * (mX // 2), N), np.nan)
+    call('mcn_filter_acts_bias_neuron_pool', d_img, d_W, d_b, d_out, d_pool, *shape_args, 0.0, 0.0, None)
+    ref, pref = d_ref.numpy(), d_pref.numpy()
+    assert np.array_equal(d_out.numpy(), ref), name      # the same per-module arithmetic
+    assert np.array_equal(d_pool.numpy(), pref), name    # pure selection
+    if N <= 128:
+        want = O.local_pool(ref, N, F, mY, mX, 2, 0, 2, mY // 2, mX // 2, 'max')
+        assert np.array_equal(pref, want), name
+
+
+@pytest.mark.parametrize('name', ['odd_k', 'cifar_conv1', 'local3', 'stride2_pad'])
+def test_filter_acts_with_pool_says_which_shapes_it_takes(name):
+    g = GEOMS[name]
+    imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, conv = g
+    N = 64
+    rng = np.random.default_rng(42)
+    d_img, d_W = dev(mk(rng, C_ * imgY * imgX, N)), dev(mk(rng, *filt_shape(g)))
+    d_b = dev(mk(rng, F * (1 if conv else mY * mX)))
+    d_out, d_pool = dev_empty((F * mY * mX, N), 0), dev_empty((F * max(1, mY // 2) * max(1, mX // 2), N), 0)
+    shape_args = (N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, groups, int(conv), 0 if conv else 1, 1)
+    L = capi.lib()
+    assert L.raw('mcn_filter_acts_pool_supported')(d_img.ptr, d_W.ptr, d_b.ptr, d_out.ptr, *shape_args) == 0
+    rc = L.raw('mcn_filter_acts_bias_neuron_pool')(d_img.ptr, d_W.ptr, d_b.ptr, d_out.ptr, d_pool.ptr, *shape_args, 0.0, 0.0, None)
+    assert rc == -1 and b'pool' in L.raw('mcn_last_error')()
+
+
 def test_filter_acts_rejects_bad_args():
     L = capi.lib()
     d = dev(np.zeros(16, np.float32))

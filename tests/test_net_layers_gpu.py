@@ -196,3 +196,21 @@ def test_early_update_on_the_side_stream_equals_the_one_launch_update_bitwise(na
                 assert np.array_equal(a, b), '%s %s[%d] differs between the early and the one-launch update' % (la['name'], key, i)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), '%s %s differs between the early and the one-launch update' % (la['name'], key)
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_pool_written_by_the_conv_launch_equals_the_separate_pool_launch_bitwise(name):
+    """A shared-weight conv layer whose (relu'd) output feeds a 2 x 2 / stride 2 max pool that tiles the maps writes the pool's
+    output in its own forward launch (ConvNet::buildFusions, mcn_filter_acts_bias_neuron_pool; MCN_NO_POOL_FUSION=1 keeps the
+    pool's launch).  Same per-module arithmetic, and a maximum has no rounding: identical weights and costs after three steps."""
+    La, ca = train3(name, {})
+    Lb, cb = train3(name, {'MCN_NO_POOL_FUSION': '1'})
+    assert ca == cb, (ca, cb)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between the fused and the separate pool' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between the fused and the separate pool' % (la['name'], key)

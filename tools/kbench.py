@@ -83,6 +83,10 @@ def main():
         nbytes = 4.0 * (img.nbytes / 4 + W.nbytes / 4 + hid.nbytes / 4)
         pre = 'mcn_conv_' if conv else 'mcn_local_'
         report(name + ' filterActs+bias+relu', (lambda: call('mcn_filter_acts_bias_neuron', img, W, b, out, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, int(conv), 0 if conv else 1, 1, 0.0, 0.0, None)), flops, nbytes)
+        if conv and mY % 2 == 0 and mX % 2 == 0:
+            pout = dev_empty((F * (mY // 2) * (mX // 2), N))
+            report(name + ' maxPool 2x2', (lambda: call('mcn_local_pool', out, pout, N, F, mY, mX, 2, 0, 2, mY // 2, mX // 2, 0, None)), 0.0, 1.25 * hid.nbytes)
+            report(name + ' filterActs+bias+relu+pool', (lambda: call('mcn_filter_acts_bias_neuron_pool', img, W, b, out, pout, N, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, int(conv), 0 if conv else 1, 1, 0.0, 0.0, None)), flops, nbytes)
         if C_ > 3:
             report(name + ' imgActs', (lambda: call(pre + 'img_acts', hid, W, dimg, N, imgY, imgX, C_, F, fs, mY, mX, pad, stride, 1, 0.0, 1.0, None)), flops, nbytes)
         if C_ > 3:  # ... and on through a 2x2 max pool + relu below (the DeepID stacks)

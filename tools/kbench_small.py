@@ -23,3 +23,29 @@ x = dev(rng.standard_normal((K, N)).astype(np.float32)); p = dev_empty((K, N), 0
 nb = max(ws_bytes('mcn_softmax_workspace_bytes', K, N), ws_bytes('mcn_logreg_cost_workspace_bytes', K, N))
 ws = capi.workspace(nb)
 show('softmax 10575 x 128', lambda: call('mcn_softmax', x, p, K, N, ws, nb, None))
+
+# ---- the multi-input FC layer (fc5): all inputs in one launch per direction, DeepID2 and DeepID2+ shapes
+import ctypes as C  # noqa: E402
+
+
+def ptr_array(bufs):
+    return (C.c_void_p * len(bufs))(*[b.ptr if b is not None else None for b in bufs])
+
+
+for tag, O_, Is in (('fc5', 160, [1024, 1200]), ('fc5+', 512, [2048, 3200])):
+    Ws = [dev((rng.standard_normal((O_, I)) * 0.02).astype(np.float32)) for I in Is]
+    Xs = [dev(np.maximum(rng.standard_normal((I, N)), 0).astype(np.float32)) for I in Is]
+    dXs = [dev_empty((I, N), 0) for I in Is]
+    dWs = [dev_empty((O_, I), 0) for I in Is]
+    b, y, dy = dev(np.zeros(O_, np.float32)), dev_empty((O_, N), 0), dev(rng.standard_normal((O_, N)).astype(np.float32))
+    wa, xa, ta_, ga, ka = ptr_array(Ws), ptr_array(Xs), ptr_array(dXs), ptr_array(dWs), (C.c_int * len(Is))(*Is)
+    zf = (C.c_float * len(Is))(*([0.0] * len(Is)))
+    one = (C.c_float * len(Is))(*([0.001] * len(Is)))
+    mom = (C.c_float * len(Is))(*([0.9] * len(Is)))
+    na, nt = ptr_array(Xs), (C.c_int * len(Is))(*([1] * len(Is)))
+    flops = 2.0 * N * O_ * sum(Is)
+    for name, fn in (('fwd (all inputs)', lambda: call('mcn_fc_fprop_multi', wa, xa, ka, len(Is), b, y, O_, N, 1, 0.0, 0.0, None)),
+                     ('bwd-data + relu grad', lambda: call('mcn_fc_bprop_acts_multi', wa, ta_, ka, zf, na, nt, zf, zf, len(Is), dy, O_, N, None)),
+                     ('bwd-weights', lambda: call('mcn_fc_bprop_weights_multi', dy, xa, ga, ka, one, mom, len(Is), O_, N, None))):
+        us = timeit(fn)
+        print('%-34s %7.2f us  %6.2f TFLOP/s' % (tag + ' ' + name, us, flops / us / 1e6), flush=True)
