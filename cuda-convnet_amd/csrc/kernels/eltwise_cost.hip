@@ -1150,6 +1150,15 @@ MCN_API int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarg
 }
 // Gradient from pair statistics and a margin that an earlier l2sn cost launch left in device memory: purely
 // elementwise (one gallery/probe element pair per thread), same arithmetic as k_l2sn<1>.
+// one (gallery, probe) element pair: d cost / d gallery element and d cost / d probe element, before the coefficient
+__device__ __forceinline__ void l2sn_grad_pair(float s1, float s2, float dist, float lab, float m, float& gx, float& gy) {
+    const float posMask = 0.5f * lab + 0.5f, negMask1 = -0.5f * lab + 0.5f;
+    const float negMask2 = dist < m ? 1.f : 0.f;
+    const float r = __fadd_rn(__fmul_rn(1.0f / dist, m), -1.0f);
+    const float diff1 = s1 - s2, diff2 = s2 - s1;
+    gx = __fadd_rn(__fmul_rn(diff2, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff1, r), negMask1), negMask2));
+    gy = __fadd_rn(__fmul_rn(diff1, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff2, r), negMask1), negMask2));
+}
 __global__ __launch_bounds__(256) void k_l2sn_grad_stats(const float* __restrict__ data, float* __restrict__ out, int numD, int numCases,
                                                           const float* __restrict__ stats, const float* __restrict__ info, int add,
                                                           float coeff) {
@@ -1157,14 +1166,8 @@ __global__ __launch_bounds__(256) void k_l2sn_grad_stats(const float* __restrict
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int k = e / h, j = e - k * h;
     if (k >= numD) return;
-    const float m = info[0], dist = stats[j], lab = stats[h + j];
-    const float posMask = 0.5f * lab + 0.5f, negMask1 = -0.5f * lab + 0.5f;
-    const float negMask2 = dist < m ? 1.f : 0.f;
-    const float r = __fadd_rn(__fmul_rn(1.0f / dist, m), -1.0f);
-    const float s1 = data[(size_t)k * numCases + j], s2 = data[(size_t)k * numCases + j + h];
-    const float diff1 = s1 - s2, diff2 = s2 - s1;
-    const float gx = __fadd_rn(__fmul_rn(diff2, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff1, r), negMask1), negMask2));
-    const float gy = __fadd_rn(__fmul_rn(diff1, posMask), __fmul_rn(__fmul_rn(__fmul_rn(diff2, r), negMask1), negMask2));
+    float gx, gy;
+    l2sn_grad_pair(data[(size_t)k * numCases + j], data[(size_t)k * numCases + j + h], stats[j], stats[h + j], info[0], gx, gy);
     float* tg = out + (size_t)k * numCases + j;
     float* tp = tg + h;
     *tg = add ? __fadd_rn(*tg, __fmul_rn(gx, coeff)) : __fmul_rn(gx, coeff);
@@ -1626,4 +1629,75 @@ MCN_API int mcn_fisher2_grad(const float* labels, const float* data, float* targ
     MCN_LAUNCH(k_fisher2_grad, dim3(divup(N, 256), numD), dim3(256), 0, s, data, (const float*)S, (const float*)r, target, numD, N, add,
                        coeff);
     return MCN_LAUNCH_CHECK("fisher2Grad");
+}
+
+// ---- the reduce pass of the classifier layer's K-split backward-data product (fc_gemm.hip: k_fc_tn_split leaves `splits` slabs of
+// M x N) that also adds the L2-SN gradient of the same matrix: mcn_fc_bprop_acts_l2sn.  The slabs are added exactly as
+// k_fc_tn_reduce adds them (eight contiguous ranges in index order, then a fixed tree), the gradient exactly as
+// k_l2sn_grad_stats(add = 1) would add it to the finished element.  The statistics may come from another stream: the threads that
+// need them wait for its stream gate here, after the slabs have been summed.
+#include "fc_gemm.h"
+typedef float f32x4_ec __attribute__((ext_vector_type(4)));
+struct TnReduceL2sn {
+    const float* part;
+    float* C;
+    int M, N, splits;
+    const float *data, *stats, *info;
+    float coeff;
+    int* gate;
+    int gateValue;
+    long long gateTicks;
+};
+__global__ __launch_bounds__(256) void k_fc_tn_reduce_l2sn(const TnReduceL2sn p) {
+    __shared__ f32x4_ec sh[8][32];
+    const f32x4_ec zero = {0.f, 0.f, 0.f, 0.f};
+    const size_t total4 = (size_t)p.M * p.N / 4;
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const size_t i = (size_t)blockIdx.x * 32 + o;
+    const bool live = i < total4;
+    const int per = (p.splits + 7) / 8, z0 = g * per, z1 = min(p.splits, z0 + per);
+    const f32x4_ec* src = reinterpret_cast<const f32x4_ec*>(p.part) + (live ? i : 0);
+    f32x4_ec s = zero;
+    for (int z = z0; z < z1; z += 8) {
+        f32x4_ec v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = z + u < z1 ? src[(size_t)(z + u) * total4] : zero;
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    sh[g][o] = s;
+    __syncthreads();
+    if (g != 0 || !live) return;
+    s = ((sh[0][o] + sh[1][o]) + (sh[2][o] + sh[3][o])) + ((sh[4][o] + sh[5][o]) + (sh[6][o] + sh[7][o]));
+    if (p.gate) {
+        const long long t0 = wall_clock64();  // 100 MHz constant clock
+        for (;;) {
+            const int v = __hip_atomic_load(p.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(v - p.gateValue) >= 0) break;
+            if (wall_clock64() - t0 > p.gateTicks) {  // (as k_stream_gate: end anyway, say so)
+                __hip_atomic_store(p.gate + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    const int h = p.N / 2;
+    const size_t e0 = i * 4;
+    const int k = (int)(e0 / p.N), n0 = (int)(e0 - (size_t)k * p.N);
+    const float m = p.info[0];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int col = n0 + t, j = col < h ? col : col - h;
+        float gx, gy;
+        l2sn_grad_pair(p.data[(size_t)k * p.N + j], p.data[(size_t)k * p.N + j + h], p.stats[j], p.stats[h + j], m, gx, gy);
+        s[t] = __fadd_rn(s[t], __fmul_rn(col < h ? gx : gy, p.coeff));
+    }
+    reinterpret_cast<f32x4_ec*>(p.C)[i] = s;
+}
+int fc_tn_reduce_l2sn_launch(const float* part, float* C, int M, int N, int splits, const FcL2snAddend& l2, hipStream_t s) {
+    TnReduceL2sn p = {part, C, M, N, splits, l2.data, l2.stats, l2.info, l2.coeff, l2.gate, l2.gateValue, (long long)l2.timeoutMs * 100000ll};
+    if (p.gate) mcn_flush_tick();  // (as mcn_stream_gate: whoever polls for an armed tick may be the one that signals the gate)
+    MCN_LAUNCH(k_fc_tn_reduce_l2sn, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
+    return MCN_LAUNCH_CHECK("gemm (fc tn reduce + l2sn grad)");
 }

@@ -505,7 +505,7 @@ int fc_nt_lds_launch(const float* A, const float* B, float* C, int M, int N, int
 }
 
 int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, int K, float alpha, float beta, void* workspace,
-                       size_t workspaceBytes, hipStream_t s) {
+                       size_t workspaceBytes, hipStream_t s, const FcL2snAddend* l2) {
     const TnPlan pl = tn_plan(M, N, K);
     const size_t need = (size_t)pl.splits * M * N * sizeof(float);
     if (!workspace || workspaceBytes < need || !al16(workspace)) {
@@ -525,6 +525,9 @@ int fc_tn_split_launch(const float* A, const float* B, float* C, int M, int N, i
     else MCN_LAUNCH((k_fc_tn_split<4, 6>), grid, dim3(256), 2 * 16 * 64 * 16, s, p);
     int rc = MCN_LAUNCH_CHECK("gemm (fc tn)");
     if (rc) return rc;
+    // (the reduce pass that also adds the L2-SN gradient lives in eltwise_cost.hip: that file is built without floating-point
+    // contraction, and the gradient has to keep the bits of k_l2sn_grad_stats)
+    if (l2) return fc_tn_reduce_l2sn_launch(p.part, C, M, N, pl.splits, *l2, s);
     MCN_LAUNCH(k_fc_tn_reduce, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc tn reduce)");
 }

@@ -409,6 +409,30 @@ MCN_API size_t mcn_gemm_workspace_bytes(int M, int N, int K, int transA, int tra
     return b;
 }
 
+// FCLayer::bpropActs (layer.cu:368-373: targets = W^T v) for a classifier layer whose input also gets the L2-SN cost's gradient
+// (L2SNCostLayer::bpropActs layer.cu:1073-1082 -> computeL2SNGrad layer_kernels.cu) as its NEXT contribution: the pass that adds
+// the product's K-split slabs adds that gradient to each finished element, after waiting (in the kernel) for the stream gate
+// that announces the cost's statistics.  Same operations in the same order as mcn_gemm(transA) followed by a gate and
+// mcn_l2sn_grad_from_stats(add = 1).
+MCN_API int mcn_fc_bprop_acts_l2sn_supported(const float* weights, const float* actsGrad, const float* targets, int numInputs,
+                                             int numCases, int numOutputs) {
+    static const bool general = getenv("MCN_GEMM_GENERAL") != nullptr;
+    return (!general && numInputs > 0 && numCases > 0 && numCases % 2 == 0 && numOutputs > 0 &&
+            fc_tn_split_usable(weights, actsGrad, targets, numInputs, numCases, numOutputs)) ? 1 : 0;
+}
+MCN_API int mcn_fc_bprop_acts_l2sn(const float* weights, const float* actsGrad, float* targets, int numInputs, int numCases,
+                                   int numOutputs, void* workspace, size_t workspaceBytes, const float* l2snData,
+                                   const float* pairStats, const float* info, float coeff, int* gate, int gateValue, int timeoutMs,
+                                   void* stream) {
+    MCN_REQUIRE(weights && actsGrad && targets && l2snData && pairStats && info, "fcBpropActsL2sn: null pointer");
+    MCN_REQUIRE(mcn_fc_bprop_acts_l2sn_supported(weights, actsGrad, targets, numInputs, numCases, numOutputs) == 1,
+                "fcBpropActsL2sn: shape outside the K-split form (mcn_fc_bprop_acts_l2sn_supported)");
+    MCN_REQUIRE(!gate || timeoutMs > 0, "fcBpropActsL2sn: a gate needs a timeout");
+    const FcL2snAddend l2 = {l2snData, pairStats, info, coeff, gate, gateValue, timeoutMs};
+    return fc_tn_split_launch(weights, actsGrad, targets, numInputs, numCases, numOutputs, 1.f, 0.f, workspace, workspaceBytes,
+                              (hipStream_t)stream, &l2);
+}
+
 static int gemm_impl(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int ta, int tb,
                      float alpha, float beta, int neuron, float na, float nb, void* workspace, size_t workspaceBytes,
                      void* stream) {

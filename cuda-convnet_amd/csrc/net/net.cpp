@@ -563,6 +563,22 @@ void FCLayer::bpropActs(float* v, int i, float scaleTargets, PassType) {
         }
     }
     float* tgt = _prev[i]->getActsGrad();
+    // the classifier layer above the feature layer: the feature layer's second gradient, from the L2-SN cost, is one elementwise
+    // pass over the same matrix and waits for a stream gate -- both go into this product's reduce launch (two launches fewer on
+    // the backward chain; MCN_NO_L2SN_FOLD=1 keeps them)
+    const bool noFold = getenv("MCN_NO_L2SN_FOLD") != nullptr;  // (read per call: tests toggle it in one process)
+    if (scaleTargets == 0 && !neuronAbove[i] && t_stream == 0 && _net->fusion() && !noFold && _prev[i]->numGradProducersNext() == 2)
+        for (Layer* l : _prev[i]->next()) {
+            auto* c = dynamic_cast<L2SNCostLayer*>(l);
+            L2SNCostLayer::Fold f;
+            if (c && c->foldable(_prev[i], f) && mcn_fc_bprop_acts_l2sn_supported(_weights[i]->W(), v, tgt, I, n, _outputs) == 1) {
+                chk(mcn_fc_bprop_acts_l2sn(_weights[i]->W(), v, tgt, I, n, _outputs, _net->workspace(), _net->workspaceBytes(), f.data,
+                                           f.stats, f.info, f.coeff, _net->gateWord(), f.gateSeq, _net->gateTimeoutMs(), _net->stream()),
+                    "fc bprop acts + l2sn grad");
+                c->gradFolded();
+                return;
+            }
+        }
     chk(mcn_gemm(_weights[i]->W(), v, tgt, I, n, _outputs, 1, 0, 1.f, scaleTargets, _net->workspace(), _net->workspaceBytes(),
                  _net->stream()), "fc bprop acts");
     if (NeuronLayer* r = neuronAbove[i])  // its gradient is this layer's job (buildFusions); scaleTargets is 0 by construction
@@ -1321,8 +1337,22 @@ void L2SNCostLayer::bprop(PassType pt) {
     if (_prev[1]->isGradConsumer()) _prev[1]->bprop(pt);
 }
 
+bool L2SNCostLayer::foldable(Layer* target, Fold& f) {
+    if (!_readyGateSeq || _earlyGrad || _readyOnExchange || _coeff == 0 || _prev.size() != 2 || _prev[1] != target) return false;
+    f.data = _prev[1]->getActs();
+    f.stats = _pairStats.p;
+    f.info = _info.p;
+    f.coeff = _coeff;
+    f.gateSeq = _readyGateSeq;
+    return true;
+}
+
 void L2SNCostLayer::bpropActs(float*, int i, float scaleTargets, PassType) {  // layer.cu:1073-1082
     if (i != 1) return;
+    if (_gradFolded) {  // the classifier layer's backward-data launch added it (FCLayer::bpropActs)
+        _gradFolded = false;
+        return;
+    }
     if (_readyGateSeq && t_stream == 0) {
         // a gate may be queued before its signal has been launched: no hand-shake with the side thread, no barrier packet
         _net->awaitGate(_readyGateSeq);

@@ -489,8 +489,14 @@ class L2SNCostLayer : public CostLayer {
     bool _readyOnExchange = false;
     int _extCount = 0;
     bool _earlyGrad = false;  // this pass already sent its gradient (forward, side stream)
+    bool _gradFolded = false; // this pass's gradient was added by the classifier layer's backward-data launch
    public:
-    void resetPassFlags() override { _earlyGrad = false; _readyTicket = 0; _readyGateSeq = 0; _readyCommGateSeq = 0; }
+    void resetPassFlags() override { _earlyGrad = false; _gradFolded = false; _readyTicket = 0; _readyGateSeq = 0; _readyCommGateSeq = 0; }
+    // The layer that sends `target` its FIRST gradient of the pass may add this layer's gradient -- the next one -- in the same
+    // launch (mcn_fc_bprop_acts_l2sn): possible when the statistics are announced by a stream gate, which that launch waits for
+    struct Fold { const float *data, *stats, *info; float coeff; int gateSeq; };
+    bool foldable(Layer* target, Fold& f);
+    void gradFolded() { _gradFolded = true; _readyGateSeq = 0; }
    protected:
 };
 
@@ -850,6 +856,8 @@ class ConvNet {
     bool _sideWaitPending = false;
    public:
     bool gatesUsable() const;
+    int* gateWord() const { return _gate; }          // the main / side stream gate (mcn_stream_gate), for launches that wait for it themselves
+    int gateTimeoutMs() const { return _gateTimeoutMs; }
     int nextGateSeq() { return ++_gateSeq; }
     void signalGate(int seq);  // on the calling thread's stream (the side stream)
     void awaitGate(int seq);   // queued on the main stream

@@ -536,6 +536,19 @@ int mcn_l2sn_grad(const float* idens, const float* data, float* dataTarget, int 
  * the margin search (layer.cu:1073-1082 calls computeL2SNGrad with the margin its fprop kept). */
 int mcn_l2sn_grad_from_stats(const float* data, float* dataTarget, int numD, int numCases, const float* pairStats,
                              const float* info, int add, float coeff, void* stream);
+/* FCLayer::bpropActs (layer.cu:368-373) of a classifier layer + the L2-SN gradient of the same input matrix
+ * (L2SNCostLayer::bpropActs layer.cu:1073-1082) in the product's own reduce pass: targets (numInputs, numCases) =
+ * weights^T actsGrad + coeff * dL2SN/d(l2snData), bitwise what mcn_gemm(transA = 1) followed by
+ * mcn_l2sn_grad_from_stats(add = 1) leaves.  weights (numOutputs, numInputs), actsGrad (numOutputs, numCases); pairStats / info
+ * as left by mcn_l2sn_pair_stats / mcn_l2sn_cost_from_stats, possibly on another stream: then gate / gateValue / timeoutMs name
+ * the stream gate (mcn_stream_signal) that announces them and the kernel waits for it itself (gate = NULL: already ordered).
+ * Shapes of the K-split form only (mcn_fc_bprop_acts_l2sn_supported = 1); workspace as mcn_gemm_workspace_bytes(.., 1, 0). */
+int mcn_fc_bprop_acts_l2sn_supported(const float* weights, const float* actsGrad, const float* targets, int numInputs,
+                                     int numCases, int numOutputs);
+int mcn_fc_bprop_acts_l2sn(const float* weights, const float* actsGrad, float* targets, int numInputs, int numCases,
+                           int numOutputs, void* workspace, size_t workspaceBytes, const float* l2snData,
+                           const float* pairStats, const float* info, float coeff, int* gate, int gateValue, int timeoutMs,
+                           void* stream);
 /* Pair distances / labels only (first half of computeL2SNCost, :517-561): pairStats[2*numCases/2].  Several workgroups, one per
  * window of 8 pairs; every distance has the bits mcn_l2sn_cost computes. */
 int mcn_l2sn_pair_stats(const float* idens, const float* data, float* pairStats, int numD, int numCases, void* stream);

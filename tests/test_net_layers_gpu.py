@@ -214,3 +214,21 @@ def test_pool_written_by_the_conv_launch_equals_the_separate_pool_launch_bitwise
                 assert np.array_equal(a, b), '%s %s[%d] differs between the fused and the separate pool' % (la['name'], key, i)
         for key in ('biases', 'biasesInc'):
             assert np.array_equal(la[key], lb[key]), '%s %s differs between the fused and the separate pool' % (la['name'], key)
+
+
+@pytest.mark.parametrize('name', PRESET_NAMES)
+def test_l2sn_gradient_added_by_the_classifier_backward_launch_equals_its_own_launch_bitwise(name):
+    """The feature layer gets two gradients: the classifier's W^T dY first, the L2-SN cost's next.  The reduce pass of the first
+    adds the second and waits for the cost's stream gate itself (FCLayer::bpropActs, mcn_fc_bprop_acts_l2sn;
+    MCN_NO_L2SN_FOLD=1 keeps the gate and the elementwise launch).  Same operations in the same order."""
+    La, ca = train3(name, {})
+    Lb, cb = train3(name, {'MCN_NO_L2SN_FOLD': '1'})
+    assert ca == cb, (ca, cb)
+    for la, lb in zip(La, Lb):
+        if 'weights' not in la:
+            continue
+        for key in ('weights', 'weightsInc'):
+            for i, (a, b) in enumerate(zip(la[key], lb[key])):
+                assert np.array_equal(a, b), '%s %s[%d] differs between the folded and the separate L2-SN gradient' % (la['name'], key, i)
+        for key in ('biases', 'biasesInc'):
+            assert np.array_equal(la[key], lb[key]), '%s %s differs between the folded and the separate L2-SN gradient' % (la['name'], key)
