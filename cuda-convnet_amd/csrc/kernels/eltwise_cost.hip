@@ -1697,7 +1697,16 @@ __global__ __launch_bounds__(256) void k_fc_tn_reduce_l2sn(const TnReduceL2sn p)
 }
 int fc_tn_reduce_l2sn_launch(const float* part, float* C, int M, int N, int splits, const FcL2snAddend& l2, hipStream_t s) {
     TnReduceL2sn p = {part, C, M, N, splits, l2.data, l2.stats, l2.info, l2.coeff, l2.gate, l2.gateValue, (long long)l2.timeoutMs * 100000ll};
+    const unsigned blocks = (unsigned)divup_sz((size_t)M * N / 4, 32);
+    if (p.gate && blocks > 1024) {
+        // Workgroups that spin hold their wave slots: a launch large enough to fill the device would keep the very kernels it
+        // waits for from starting.  (The same fold for the weight update -- thousands of workgroups -- ran into exactly that: the
+        // side stream starved and the gate timed out.)  Large outputs get the one-thread gate launch in front instead.
+        int rc = mcn_stream_gate(p.gate, p.gateValue, l2.timeoutMs, s);
+        if (rc) return rc;
+        p.gate = nullptr;
+    }
     if (p.gate) mcn_flush_tick();  // (as mcn_stream_gate: whoever polls for an armed tick may be the one that signals the gate)
-    MCN_LAUNCH(k_fc_tn_reduce_l2sn, dim3((unsigned)divup_sz((size_t)M * N / 4, 32)), dim3(256), 0, s, p);
+    MCN_LAUNCH(k_fc_tn_reduce_l2sn, dim3(blocks), dim3(256), 0, s, p);
     return MCN_LAUNCH_CHECK("gemm (fc tn reduce + l2sn grad)");
 }
