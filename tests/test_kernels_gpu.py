@@ -43,6 +43,8 @@ GEOMS = {
     'odd_k': (9, 9, 1, 16, 3, 7, 7, 0, 1, 1, True),
     'wide_pad_stride': (11, 9, 32, 128, 3, 6, 5, -1, 2, 1, True),   # k_weight_acts_wide with padding checks and stride 2
     'wide_local_pad': (6, 6, 32, 256, 2, 7, 7, -1, 1, 1, False),    # ... KV = 4 (K = 128), two filter blocks, unshared
+    'conv_odd_quads': (20, 20, 4, 16, 3, 18, 18, 0, 1, 1, True),    # 81 pool windows: the last strip / workgroup of the pool-fused forward is partial
+    'conv_odd_quads_f64': (20, 20, 4, 64, 3, 18, 18, 0, 1, 1, True),
 }
 
 
@@ -134,7 +136,8 @@ def test_filter_acts_bias_neuron(name, per_module):
 # the forward launch that also writes the 2 x 2 max pool of its output: strips of 1, 2, 4 and 8 modules (quads shared by 4 / 2 / 1
 # waves), filter vectors of 1-4 tiles, ragged image tiles
 @pytest.mark.parametrize('name,N', [('conv2', 128), ('conv1_55', 128), ('conv1_55', 256), ('conv1_55', 512), ('conv1_plus', 128),
-                                    ('conv2_plus', 128), ('conv_f48', 448), ('conv2_39x31', 100), ('conv1_39x31', 4), ('conv2', 96)])
+                                    ('conv2_plus', 128), ('conv_f48', 448), ('conv2_39x31', 100), ('conv1_39x31', 4), ('conv2', 96),
+                                    ('conv_odd_quads_f64', 1024), ('conv_odd_quads', 2048), ('conv_odd_quads', 4096), ('groups2', 128)])
 @pytest.mark.parametrize('neuron', [1, 0])
 def test_filter_acts_with_the_max_pool_in_the_same_launch(name, N, neuron):
     g = GEOMS[name]
