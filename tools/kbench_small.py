@@ -49,3 +49,13 @@ for tag, O_, Is in (('fc5', 160, [1024, 1200]), ('fc5+', 512, [2048, 3200])):
                      ('bwd-weights', lambda: call('mcn_fc_bprop_weights_multi', dy, xa, ga, ka, one, mom, len(Is), O_, N, None))):
         us = timeit(fn)
         print('%-34s %7.2f us  %6.2f TFLOP/s' % (tag + ' ' + name, us, flops / us / 1e6), flush=True)
+
+# ---- the bias gradients: row sums (mcn_add_sum, the code k_row_sums_multi runs per matrix)
+for tag, rows, cols in (('conv2 bias', 32, 576 * N), ('local3 bias', 4800, N), ('local4 bias', 1024, N), ('fc6 bias', K, N),
+                        ('conv2+ bias', 128, 576 * N), ('local3+ bias', 12800, N), ('local4+ bias', 2048, N)):
+    m = dev(rng.standard_normal((rows, cols)).astype(np.float32))
+    t = dev_empty((rows,), 0)
+    wsb = ws_bytes('mcn_add_sum_workspace_bytes', rows, cols, 1)
+    w = capi.workspace(max(wsb, 16))
+    us = timeit(lambda: call('mcn_add_sum', t, m, rows, cols, 1, 0.0, 1.0, w, wsb, None))
+    print('%-34s %7.2f us  %7.1f GB/s' % (tag + ' row sum', us, rows * cols * 4 / us / 1e3), flush=True)
